@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 160x160 lip-sync frames/sec through the MI355X engine.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+A "step" is one pass of the hot path (``Model.forward``) over one batch of synthetic
+frames per GPU.  Workload = BASELINE.json configs[1]: batch 64 per GPU, 160x160 fp32,
+synthetic crops U(0,1) + random HuBERT windows N(0,1) (the reference's own self-benchmark
+shapes, image_infer_v1/models/unet.py:342-347), golden-recipe weights.  Inputs are
+resident in HBM before the timed region; outputs stay on the device.
+
+N > 1: one process per GPU (torch.distributed, backend "nccl" == RCCL).  Frames are
+independent, so the batch is sharded with no data-path collective ("weak" scaling: 64
+frames per GPU); the only collective is ONE broadcast of the packed, BN-folded weight
+buffer from rank 0 at start-up.
+
+Prints one JSON line (rank 0) with the whole-job frames/sec, the roofline of the dominant
+kernel (live HIP-event timing) and, at N=1, the CPU oracle timed on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: f32-input MFMA == f32 vector peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--kernel-table", action="store_true", help="print the per-launch table to stderr")
+    return ap.parse_args()
+
+
+def kernel_class(name: str) -> str:
+    """Group the plan's launches by the HIP kernel that runs them."""
+    if name.endswith(".dw"):
+        return "dw3x3_kernel"
+    if name.endswith(".attn"):
+        return "cross_attention_kernel"
+    if name.endswith(".im2col"):
+        return "im2col3x3_kernel"
+    if name.endswith(".bilinear"):
+        return "upsample2x_kernel"
+    if name in ("inc", "outc", "audio.nchw_to_nhwc"):
+        return name + "_kernel"
+    return "pw_gemm_f32_kernel"
+
+
+def cpu_baseline(sd_np, seconds: float):
+    """The CPU oracle (a port of the reference's forward, torch-CPU fp32) on the host cores."""
+    from calipsync_amd import recipe
+    from oracle import unet_oracle
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    sd = unet_oracle.to_torch(sd_np)
+    b = 8
+    x, a = recipe.make_inputs(b)
+    xt, at = torch.from_numpy(x), torch.from_numpy(a)
+    unet_oracle.forward(sd, xt, at)                      # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        unet_oracle.forward(sd, xt, at)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 50:
+            break
+    return {"value": round(n * b / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} forwards of batch {b} (same weights/input recipe), torch-CPU fp32, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path to benchmark")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from calipsync_amd import arch, recipe, _lib
+    from calipsync_amd.unet import Model
+    from calipsync_amd.sharding import broadcast_packed_weights, shard_range
+
+    # ---- weights: rank 0 folds + packs, ONE RCCL broadcast, every rank adopts the buffer
+    sd_np = recipe.make_state_dict() if rank == 0 else None
+    net = Model(6, "hubert").to(dev)
+    if rank == 0:
+        net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    packed = broadcast_packed_weights(net if rank == 0 else None, dev)
+    net.adopt_packed(packed)
+
+    # ---- inputs: this rank's contiguous shard of the global synthetic batch, resident in HBM
+    B = args.batch
+    start, count = shard_range(B * world, rank, world)
+    x_np, a_np = recipe.make_inputs_range(start, count)
+    x, a = torch.from_numpy(x_np).to(dev), torch.from_numpy(a_np).to(dev)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        out = net(x, a)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = net(x, a)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out).all()
+
+    # ---- per-kernel timing with HIP events on the launch stream (rank 0)
+    result = None
+    if rank == 0:
+        per = {}
+        reps = 3
+        for _ in range(reps):
+            for row in net.profile(x, a):
+                c = per.setdefault(kernel_class(row["name"]), {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
+                c["ms"] += row["ms"]; c["flops"] += row["flops"]; c["bytes"] += row["bytes"]; c["n"] += 1
+        if args.kernel_table:
+            tot = sum(c["ms"] for c in per.values())
+            for k, c in sorted(per.items(), key=lambda kv: -kv[1]["ms"]):
+                print(f"{k:28s} {c['n'] // reps:4d} launches {c['ms'] / reps:9.3f} ms {100 * c['ms'] / tot:5.1f}%  "
+                      f"{c['flops'] / c['ms'] / 1e9:8.1f} TFLOP/s {c['bytes'] / c['ms'] / 1e6:8.1f} GB/s", file=sys.stderr)
+            rows = net.profile(x, a)
+            for r in rows:
+                print(f"  {r['name']:48s} {r['ms']:8.3f} ms {r['flops'] / max(r['ms'], 1e-6) / 1e9:8.1f} TF "
+                      f"{r['bytes'] / max(r['ms'], 1e-6) / 1e6:8.1f} GB/s", file=sys.stderr)
+        dom_name, dom = max(per.items(), key=lambda kv: kv[1]["ms"])
+        tf = dom["flops"] / dom["ms"] / 1e9
+        gbs = dom["bytes"] / dom["ms"] / 1e6
+        mfma_bound = dom_name == "pw_gemm_f32_kernel" and tf / MFMA_F32_PEAK_TF >= gbs / HBM_PEAK_GBS
+        roofline = {
+            "kernel": dom_name,
+            "bound": "mfma" if mfma_bound else "hbm",
+            "achieved": round(tf if mfma_bound else gbs, 2),
+            "peak": MFMA_F32_PEAK_TF if mfma_bound else HBM_PEAK_GBS,
+            "unit": "TFLOP/s" if mfma_bound else "GB/s",
+            "frac": round((tf / MFMA_F32_PEAK_TF) if mfma_bound else (gbs / HBM_PEAK_GBS), 4),
+            "traffic": None,
+            "launches_per_step": dom["n"] // reps,
+            "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
+            "share_of_step": round(dom["ms"] / sum(c["ms"] for c in per.values()), 3),
+        }
+        work = arch.work_per_frame()
+        fps = world * B * args.steps / dt
+        per_gpu = fps / world
+        result = {
+            "metric": "160x160 lip-sync frames/sec (whole node)",
+            "value": round(fps, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"batch={B}/GPU 160x160 fp32 crops + HuBERT windows through Model.forward "
+                                   "(BASELINE configs[1]); frames sharded, weights broadcast once",
+                       "global_batch": B * world, "parallelism": f"frames-dp{world}"},
+            "roofline": roofline,
+            "whole_net": {"mfma_frac": round(per_gpu * work["flops"] / (MFMA_F32_PEAK_TF * 1e12), 4),
+                          "hbm_frac_canonical": round(per_gpu * work["canonical_bytes_f32"] / (HBM_PEAK_GBS * 1e9), 4),
+                          "gflop_per_frame": round(work["flops"] / 1e9, 3),
+                          "canonical_mb_per_frame": round(work["canonical_bytes_f32"] / 1e6, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(sd_np, args.cpu_seconds)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,98 @@
+"""ctypes binding of libcasync_hip.so (include/casync_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, a
+RuntimeError is raised with the library's own message."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from . import build as _build
+
+_lib: Optional[C.CDLL] = None
+
+c_f32p = C.c_void_p       # device pointers travel as integers
+c_i64 = C.c_int64
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("ms", C.c_float), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+_PROTOS = {
+    "casync_abi_version": (C.c_int, []),
+    "casync_last_error": (C.c_char_p, []),
+    "casync_packed_count": (C.c_int, []),
+    "casync_packed_name": (C.c_char_p, [C.c_int]),
+    "casync_packed_offset": (c_i64, [C.c_int]),
+    "casync_packed_size": (c_i64, [C.c_int]),
+    "casync_packed_total": (c_i64, []),
+    "casync_workspace_bytes": (c_i64, [C.c_int]),
+    "casync_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "casync_destroy": (None, [C.c_void_p]),
+    "casync_load_weights_host": (C.c_int, [C.c_void_p, C.c_void_p, c_i64]),
+    "casync_load_weights_device": (C.c_int, [C.c_void_p, c_f32p, c_i64]),
+    "casync_forward": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_void_p, c_i64,
+                                 C.c_void_p]),
+    "casync_tap": (c_i64, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, c_f32p, c_i64, C.c_void_p]),
+    "casync_profile_forward": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_void_p,
+                                         c_i64, C.c_void_p, C.POINTER(KernelTime), C.c_int]),
+    "casync_op_pw_gemm": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_f32p, c_f32p,
+                                    C.c_int, c_f32p, c_f32p, C.c_void_p]),
+    "casync_op_dw3x3": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.c_void_p]),
+    "casync_op_im2col3x3": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_void_p]),
+    "casync_op_upsample2x": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p]),
+    "casync_op_cross_attention": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int,
+                                            c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int,
+                                            C.c_void_p]),
+    "casync_op_nchw_to_nhwc": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "casync_op_inc": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_void_p]),
+    "casync_op_outc": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_void_p]),
+}
+
+EXPORTS = tuple(_PROTOS)
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the engine library or raise -- there is no CPU / eager fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"casync HIP engine not built: {path} is missing. Run `python -c 'import "
+            "__graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)       # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> int:
+    if status < 0:
+        msg = load().casync_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (status {status}): {msg}")
+    return status
+
+
+def packed_layout():
+    """[(name, offset, size)] in floats, and the total -- the engine owns the layout."""
+    lib = load()
+    n = lib.casync_packed_count()
+    items = [(lib.casync_packed_name(i).decode(), lib.casync_packed_offset(i),
+              lib.casync_packed_size(i)) for i in range(n)]
+    return items, lib.casync_packed_total()

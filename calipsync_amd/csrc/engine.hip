@@ -1,0 +1,577 @@
+// The forward plan of the CASync U-Net on one MI355X: packed-weight layout, workspace
+// arena and the launch sequence that replaces Model.forward (reference
+// module/unet.py:314-345).  Mirrors calipsync_amd/arch.py (tests/test_abi.py checks the two
+// agree).  Everything is NHWC fp32 inside; NCHW only at the boundary.
+#include <stdarg.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+// ------------------------------------------------------------------ error text
+static thread_local char g_err[512] = "";
+void casync_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* casync_last_error(void) { return g_err; }
+
+namespace {
+
+// ------------------------------------------------------------------ architecture table
+struct IR {  // inverted residual: PW expand -> DW3x3 -> PW project (module/unet.py:8-40)
+  const char* prefix;
+  int cin, cout, stride, res, hw_in;
+  int cexp() const { return cin * 2; }
+  int hw_out() const { return stride == 1 ? hw_in : (hw_in + 2 - 3) / 2 + 1; }
+};
+
+const IR kInc = {"inc.inconv.0", 6, 32, 1, 0, 160};
+const IR kDown[4][2] = {
+    {{"down1.maxpool_conv.0.double_conv.0", 32, 64, 2, 0, 160}, {"down1.maxpool_conv.0.double_conv.1", 64, 64, 1, 1, 80}},
+    {{"down2.maxpool_conv.0.double_conv.0", 64, 128, 2, 0, 80}, {"down2.maxpool_conv.0.double_conv.1", 128, 128, 1, 1, 40}},
+    {{"down3.maxpool_conv.0.double_conv.0", 128, 256, 2, 0, 40}, {"down3.maxpool_conv.0.double_conv.1", 256, 256, 1, 1, 20}},
+    {{"down4.maxpool_conv.0.double_conv.0", 256, 512, 2, 0, 20}, {"down4.maxpool_conv.0.double_conv.1", 512, 512, 1, 1, 10}}};
+const IR kAudio[5] = {{"audio_model.conv1", 32, 64, 1, 0, 32},
+                      {"audio_model.conv2", 64, 128, 1, 0, 32},
+                      {"audio_model.conv4", 256, 256, 1, 1, 16},
+                      {"audio_model.conv6", 512, 512, 1, 1, 10},
+                      {"audio_model.conv7", 512, 512, 1, 1, 10}};
+const IR kFuse[4] = {{"fuse_conv.0.double_conv.0", 1024, 512, 1, 0, 10},
+                     {"fuse_conv.0.double_conv.1", 512, 512, 1, 1, 10},
+                     {"fuse_conv.1.double_conv.0", 512, 256, 1, 0, 10},
+                     {"fuse_conv.1.double_conv.1", 256, 256, 1, 1, 10}};
+const IR kUp[4][2] = {
+    {{"up1.conv.double_conv.0", 512, 128, 1, 0, 20}, {"up1.conv.double_conv.1", 128, 128, 1, 1, 20}},
+    {{"up2.conv.double_conv.0", 256, 64, 1, 0, 40}, {"up2.conv.double_conv.1", 64, 64, 1, 1, 40}},
+    {{"up3.conv.double_conv.0", 128, 32, 1, 0, 80}, {"up3.conv.double_conv.1", 32, 32, 1, 1, 80}},
+    {{"up4.conv.double_conv.0", 64, 32, 1, 0, 160}, {"up4.conv.double_conv.1", 32, 32, 1, 1, 160}}};
+constexpr int kBlocks = 4;          // attention blocks
+constexpr int kKV = 64 + 512;       // per-block [K | V] projection columns
+
+// ------------------------------------------------------------------ packed weights
+struct Packed {
+  std::string name;
+  int64_t offset, size;
+};
+
+struct Layout {
+  std::vector<Packed> items;
+  int64_t total = 0;
+  void add(const std::string& name, int64_t size) {
+    items.push_back({name, total, size});
+    total += (size + 63) / 64 * 64;  // 256-B aligned tensors
+  }
+  void add_ir(const IR& b) {
+    const std::string p = b.prefix;
+    add(p + ".pw1.w", (int64_t)b.cexp() * b.cin);
+    add(p + ".pw1.b", b.cexp());
+    add(p + ".dw.w", 9 * (int64_t)b.cexp());
+    add(p + ".dw.b", b.cexp());
+    add(p + ".pw2.w", (int64_t)b.cout * b.cexp());
+    add(p + ".pw2.b", b.cout);
+  }
+  int64_t off(const std::string& name) const {
+    for (const auto& it : items)
+      if (it.name == name) return it.offset;
+    return -1;
+  }
+};
+
+const Layout& layout() {
+  static const Layout L = [] {
+    Layout l;
+    l.add("inc.inconv.0.fused", 620);  // [w1 12x6][b1 12][wd 9x12][bd 12][w2 32x12][b2 32]
+    for (auto& st : kDown)
+      for (auto& b : st) l.add_ir(b);
+    l.add_ir(kAudio[0]);
+    l.add_ir(kAudio[1]);
+    l.add("audio_model.conv3.w", 256ll * 9 * 128);  // [N][(ky,kx,cin)]
+    l.add("audio_model.conv3.b", 256);
+    l.add_ir(kAudio[2]);
+    l.add("audio_model.conv5.w", 512ll * 9 * 256);
+    l.add("audio_model.conv5.b", 512);
+    l.add_ir(kAudio[3]);
+    l.add_ir(kAudio[4]);
+    l.add("audio_model.bn7.s", 512);
+    l.add("audio_model.bn7.t", 512);
+    l.add("mlp_fusion.fc1.w", 1024ll * 1024);
+    l.add("mlp_fusion.fc1.b", 1024);
+    l.add("mlp_fusion.fc2.w", 1024ll * 1024);  // bn2 and bn_tx folded in
+    l.add("mlp_fusion.fc2.b", 1024);
+    l.add("mlp_fusion.fc2.rs", 1024);          // bn_tx scale on the cat(x5, a) residual
+    l.add("att.kv.w", (int64_t)kBlocks * kKV * 512);  // rows: blk0 K(64) V(512), blk1 ...
+    l.add("att.kv.b", kBlocks * kKV);
+    for (int i = 0; i < kBlocks; ++i) {
+      const std::string p = "attention_blocks." + std::to_string(i);
+      l.add(p + ".p1.w", 512ll * 1024);
+      l.add(p + ".p1.b", 512);
+      l.add(p + ".q.w", 64ll * 512);
+      l.add(p + ".q.b", 64);
+      l.add(p + ".gamma", 1);
+      l.add(p + ".b1.w", 1024ll * 512);  // block bn folded in
+      l.add(p + ".b1.b", 1024);
+      l.add(p + ".b1.rs", 1024);         // block bn scale on the tx residual
+    }
+    l.add("bn_kx.s", 1024);
+    l.add("bn_kx.t", 1024);
+    for (auto& b : kFuse) l.add_ir(b);
+    for (auto& st : kUp)
+      for (auto& b : st) l.add_ir(b);
+    l.add("outc.w", 96);  // [3][32], outc_bn folded in
+    l.add("outc.b", 3);
+    return l;
+  }();
+  return L;
+}
+
+// ------------------------------------------------------------------ workspace arena
+struct Arena {
+  // per-frame float counts; pointers are filled by bind()
+  struct Buf {
+    const char* name;
+    int64_t per_frame;
+    float* p;
+  };
+  enum Id {
+    CAT4, CAT3, CAT2, CAT1, CATA, E1, E2, T0, U4, F, FM, U1, U2, U3,
+    A0, AC1, AC2, IM, AC3, AC4, AC5, AC6, AE1, AE2,
+    H, TX, OX0, OX1, OX2, OX3, KX, KXF, P1, AO, Q, KV, COUNT
+  };
+  Buf b[COUNT] = {
+      {"cat4", 160 * 160 * 64, 0},  {"cat3", 80 * 80 * 128, 0},  {"cat2", 40 * 40 * 256, 0},
+      {"cat1", 20 * 20 * 512, 0},   {"catA", 100 * 1024, 0},     {"E1", 160 * 160 * 128, 0},
+      {"E2", 160 * 160 * 128, 0},   {"T0", 160 * 160 * 32, 0},   {"U4", 160 * 160 * 32, 0},
+      {"F", 100 * 256, 0},          {"FM", 100 * 512, 0},        {"U1", 400 * 128, 0},
+      {"U2", 1600 * 64, 0},         {"U3", 6400 * 32, 0},        {"A0", 1024 * 32, 0},
+      {"AC1", 1024 * 64, 0},        {"AC2", 1024 * 128, 0},      {"IM", 256 * 1152, 0},
+      {"AC3", 256 * 256, 0},        {"AC4", 256 * 256, 0},       {"AC5", 100 * 512, 0},
+      {"AC6", 100 * 512, 0},        {"AE1", 131072, 0},          {"AE2", 131072, 0},
+      {"H", 100 * 1024, 0},         {"TX", 100 * 1024, 0},       {"OX0", 100 * 1024, 0},
+      {"OX1", 100 * 1024, 0},       {"OX2", 100 * 1024, 0},      {"OX3", 100 * 1024, 0},
+      {"KX", 100 * 1024, 0},        {"KXF", 100 * 1024, 0},      {"P1", 100 * 512, 0},
+      {"AO", 100 * 512, 0},         {"Q", 100 * 64, 0},          {"KV", 100 * kBlocks * kKV, 0}};
+  static int64_t bytes(int batch) {
+    Arena a;
+    int64_t tot = 0;
+    for (auto& x : a.b) tot += (x.per_frame * batch + 63) / 64 * 64;
+    return tot * (int64_t)sizeof(float);
+  }
+  void bind(void* base, int batch) {
+    float* p = (float*)base;
+    for (auto& x : b) {
+      x.p = p;
+      p += (x.per_frame * batch + 63) / 64 * 64;
+    }
+  }
+  float* operator[](Id i) const { return b[i].p; }
+};
+
+}  // namespace
+
+struct casync_engine {
+  int device = 0;
+  const float* w = nullptr;  // packed weights on the device
+  float* owned = nullptr;
+  const float* W(const std::string& name) const { return w + layout().off(name); }
+};
+
+namespace {
+
+// ------------------------------------------------------------------ launch recorder
+struct Runner {
+  hipStream_t s;
+  bool profile = false;
+  std::vector<casync_kernel_time> rec;
+  std::vector<hipEvent_t> ev;
+  int status = CASYNC_OK;
+
+  template <class F>
+  void run(const char* name, double flops, double bytes, F&& f) {
+    if (status != CASYNC_OK) return;
+    if (profile) {
+      hipEvent_t a, b;
+      (void)hipEventCreate(&a);
+      (void)hipEventCreate(&b);
+      (void)hipEventRecord(a, s);
+      status = f();
+      (void)hipEventRecord(b, s);
+      ev.push_back(a);
+      ev.push_back(b);
+      casync_kernel_time t;
+      memset(&t, 0, sizeof(t));
+      strncpy(t.name, name, sizeof(t.name) - 1);
+      t.flops = flops;
+      t.bytes = bytes;
+      rec.push_back(t);
+    } else {
+      status = f();
+    }
+  }
+  void finish() {
+    if (!profile) return;
+    (void)hipStreamSynchronize(s);
+    for (size_t i = 0; i < rec.size(); ++i) {
+      (void)hipEventElapsedTime(&rec[i].ms, ev[2 * i], ev[2 * i + 1]);
+      (void)hipEventDestroy(ev[2 * i]);
+      (void)hipEventDestroy(ev[2 * i + 1]);
+    }
+  }
+};
+
+struct Plan {
+  const casync_engine& e;
+  Arena ar;
+  Runner& r;
+  int B;
+
+  // GEMM wrapper with work accounting (algorithmic bytes: A + C once, W once)
+  void gemm(const std::string& tag, const float* a, int lda, const std::string& wname, float* c,
+            int ldc, long long m, int n, int k, GemmEpilogue epi, const std::string& bname = "") {
+    const float* w = e.W(wname);
+    epi.bias = e.W(bname.empty() ? wname.substr(0, wname.size() - 1) + "b" : bname);
+    double bytes = 4.0 * ((double)m * k + (double)m * n + (double)n * k);
+    if (epi.pre_res) bytes += 4.0 * m * n;
+    if (epi.post_res) bytes += 4.0 * m * n;
+    if (epi.acc_out) bytes += 8.0 * m * n;
+    r.run(tag.c_str(), 2.0 * m * n * k, bytes,
+          [&] { return launch_pw_gemm(a, lda, w, c, ldc, (int)m, n, k, epi, r.s); });
+  }
+
+  // One inverted-residual block.  in: [B*hw_in^2, cin] (ld_in); out: [B*hw_out^2, cout] (ld_out).
+  void ir(const IR& b, const float* in, int ld_in, float* out, int ld_out, float* e1, float* e2,
+          const GemmEpilogue* extra = nullptr) {
+    const std::string p = b.prefix;
+    const long long m_in = (long long)B * b.hw_in * b.hw_in, m_out = (long long)B * b.hw_out() * b.hw_out();
+    GemmEpilogue ep1;
+    ep1.act = 1;
+    gemm(p + ".pw1", in, ld_in, p + ".pw1.w", e1, b.cexp(), m_in, b.cexp(), b.cin, ep1);
+    r.run((p + ".dw").c_str(), 2.0 * 9 * m_out * b.cexp(), 4.0 * (m_in + m_out) * b.cexp(), [&] {
+      return launch_dw3x3(e1, e.W(p + ".dw.w"), e.W(p + ".dw.b"), e2, B, b.hw_in, b.hw_in, b.cexp(),
+                          b.stride, r.s);
+    });
+    GemmEpilogue ep2;
+    if (extra) ep2 = *extra;
+    ep2.act = 1;
+    if (b.res) {
+      ep2.post_res = in;
+      ep2.ld_post = ld_in;
+    }
+    gemm(p + ".pw2", e2, b.cexp(), p + ".pw2.w", out, ld_out, m_out, b.cout, b.cexp(), ep2);
+  }
+
+  void forward(const float* x, const float* audio, float* out) {
+    using A = Arena;
+    float *E1 = ar[A::E1], *E2 = ar[A::E2], *T0 = ar[A::T0];
+    // ---------------- face encoder (module/unet.py:315-319)
+    r.run("inc", 2.0 * B * 25600 * (72 + 108 + 384), 4.0 * B * 25600 * (6 + 32), [&] {
+      return launch_inc(x, e.W("inc.inconv.0.fused"), ar[A::CAT4] + 32, 64, B, r.s);
+    });
+    struct Skip { float* p; int ld; };
+    const Skip sk[5] = {{ar[A::CAT4] + 32, 64},   {ar[A::CAT3] + 64, 128}, {ar[A::CAT2] + 128, 256},
+                        {ar[A::CAT1] + 256, 512}, {ar[A::CATA], 1024}};
+    for (int i = 0; i < 4; ++i) {
+      ir(kDown[i][0], sk[i].p, sk[i].ld, T0, kDown[i][0].cout, E1, E2);
+      ir(kDown[i][1], T0, kDown[i][1].cin, sk[i + 1].p, sk[i + 1].ld, E1, E2);
+    }
+    // ---------------- audio encoder (module/unet.py:177-194)
+    float *AE1 = ar[A::AE1], *AE2 = ar[A::AE2];
+    r.run("audio.nchw_to_nhwc", 0, 8.0 * B * 32768,
+          [&] { return launch_nchw_to_nhwc(audio, ar[A::A0], B, 32, 1024, r.s); });
+    ir(kAudio[0], ar[A::A0], 32, ar[A::AC1], 64, AE1, AE2);
+    ir(kAudio[1], ar[A::AC1], 64, ar[A::AC2], 128, AE1, AE2);
+    r.run("audio.conv3.im2col", 0, 4.0 * B * (131072 + 256 * 1152), [&] {
+      return launch_im2col3x3(ar[A::AC2], ar[A::IM], B, 32, 32, 128, 2, 1, r.s);
+    });
+    {
+      GemmEpilogue ep;
+      ep.act = 1;
+      gemm("audio.conv3", ar[A::IM], 1152, "audio_model.conv3.w", ar[A::AC3], 256, (long long)B * 256, 256, 1152, ep);
+    }
+    ir(kAudio[2], ar[A::AC3], 256, ar[A::AC4], 256, AE1, AE2);
+    r.run("audio.conv5.im2col", 0, 4.0 * B * (65536 + 100 * 2304), [&] {
+      return launch_im2col3x3(ar[A::AC4], ar[A::IM], B, 16, 16, 256, 2, 3, r.s);
+    });
+    {
+      GemmEpilogue ep;
+      ep.act = 1;
+      gemm("audio.conv5", ar[A::IM], 2304, "audio_model.conv5.w", ar[A::AC5], 512, (long long)B * 100, 512, 2304, ep);
+    }
+    ir(kAudio[3], ar[A::AC5], 512, ar[A::AC6], 512, AE1, AE2);
+    {
+      GemmEpilogue bn7;  // relu7(bn7(x + conv(x))) fused behind conv7's residual add
+      bn7.aff_s = e.W("audio_model.bn7.s");
+      bn7.aff_t = e.W("audio_model.bn7.t");
+      ir(kAudio[4], ar[A::AC6], 512, ar[A::CATA] + 512, 1024, AE1, AE2, &bn7);
+    }
+    // ---------------- fusion (module/unet.py:323-326): tx = bn_tx(cat + mlp(cat))
+    const long long M10 = (long long)B * 100;
+    float* CATA = ar[A::CATA];
+    {
+      GemmEpilogue ep;
+      ep.act = 1;
+      gemm("mlp.fc1", CATA, 1024, "mlp_fusion.fc1.w", ar[A::H], 1024, M10, 1024, 1024, ep);
+      GemmEpilogue ep2;
+      ep2.pre_res = CATA;
+      ep2.ld_pre = 1024;
+      ep2.pre_scale = e.W("mlp_fusion.fc2.rs");
+      gemm("mlp.fc2", ar[A::H], 1024, "mlp_fusion.fc2.w", ar[A::TX], 1024, M10, 1024, 1024, ep2);
+    }
+    // K and V projections of the audio features for all four blocks in one GEMM
+    gemm("att.kv", CATA + 512, 1024, "att.kv.w", ar[A::KV], kBlocks * kKV, M10, kBlocks * kKV, 512, GemmEpilogue());
+    // ---------------- attention blocks (module/unet.py:331-336)
+    float* ox[4] = {ar[A::OX0], ar[A::OX1], ar[A::OX2], ar[A::OX3]};
+    const float* prev = ar[A::TX];
+    for (int i = 0; i < kBlocks; ++i) {
+      const std::string p = "attention_blocks." + std::to_string(i);
+      gemm(p + ".p1", prev, 1024, p + ".p1.w", ar[A::P1], 512, M10, 512, 1024, GemmEpilogue());
+      gemm(p + ".q", ar[A::P1], 512, p + ".q.w", ar[A::Q], 64, M10, 64, 512, GemmEpilogue());
+      const float* kv = ar[A::KV] + i * kKV;
+      r.run((p + ".attn").c_str(), 2.0 * M10 * 100 * (64 + 512), 4.0 * M10 * (64 + kKV + 1024), [&] {
+        return launch_cross_attention(ar[A::Q], 64, kv, kBlocks * kKV, kv + 64, kBlocks * kKV, ar[A::P1],
+                                      512, e.W(p + ".gamma"), ar[A::AO], 512, B, r.s);
+      });
+      GemmEpilogue ep;  // lrelu(bn(b_1(ox) + tx)); kx += ox; last block also lrelu(bn_kx(kx))
+      ep.pre_res = ar[A::TX];
+      ep.ld_pre = 1024;
+      ep.pre_scale = e.W(p + ".b1.rs");
+      ep.act = 1;
+      ep.acc_in = i == 0 ? ar[A::TX] : ar[A::KX];
+      ep.acc_out = i == kBlocks - 1 ? ar[A::KXF] : ar[A::KX];
+      ep.ld_acc = 1024;
+      if (i == kBlocks - 1) {
+        ep.aff_s = e.W("bn_kx.s");
+        ep.aff_t = e.W("bn_kx.t");
+        ep.aff_on_acc = 1;
+      }
+      gemm(p + ".b1", ar[A::AO], 512, p + ".b1.w", ox[i], 1024, M10, 1024, 512, ep);
+      prev = ox[i];
+    }
+    // ---------------- fuse_conv (module/unet.py:337)
+    ir(kFuse[0], ar[A::KXF], 1024, T0, 512, E1, E2);
+    ir(kFuse[1], T0, 512, ar[A::FM], 512, E1, E2);
+    ir(kFuse[2], ar[A::FM], 512, T0, 256, E1, E2);
+    ir(kFuse[3], T0, 256, ar[A::F], 256, E1, E2);
+    // ---------------- decoder (module/unet.py:338-341)
+    const float* lo = ar[A::F];
+    float* cat[4] = {ar[A::CAT1], ar[A::CAT2], ar[A::CAT3], ar[A::CAT4]};
+    float* uo[4] = {ar[A::U1], ar[A::U2], ar[A::U3], ar[A::U4]};
+    int hw = 10, c = 256;
+    for (int i = 0; i < 4; ++i) {
+      const int cc = 2 * c;  // concat width
+      r.run(("up" + std::to_string(i + 1) + ".bilinear").c_str(), 0, 4.0 * B * hw * hw * c * 5, [&] {
+        return launch_upsample2x(lo, cat[i], cc, B, hw, hw, c, r.s);
+      });
+      ir(kUp[i][0], cat[i], cc, T0, kUp[i][0].cout, E1, E2);
+      ir(kUp[i][1], T0, kUp[i][1].cin, uo[i], kUp[i][1].cout, E1, E2);
+      lo = uo[i];
+      hw *= 2;
+      c = kUp[i][1].cout;
+    }
+    // ---------------- head (module/unet.py:342-344)
+    r.run("outc", 2.0 * B * 25600 * 96, 4.0 * B * 25600 * 35, [&] {
+      return launch_outc(ar[A::U4], 32, e.W("outc.w"), e.W("outc.b"), out, B, r.s);
+    });
+  }
+};
+
+int check_forward_args(casync_handle h, const float* x, const float* a, float* out, int batch,
+                       void* ws, int64_t ws_bytes) {
+  CASYNC_REQUIRE(h, "null handle");
+  CASYNC_REQUIRE(x && a && out && ws, "forward: null pointer");
+  CASYNC_REQUIRE(batch > 0 && batch <= 8192, "forward: batch %d out of range [1, 8192]", batch);
+  if (!h->w) {
+    casync_set_error("forward: weights not loaded");
+    return CASYNC_ERR_STATE;
+  }
+  if (ws_bytes < Arena::bytes(batch)) {
+    casync_set_error("forward: workspace %lld B < required %lld B", (long long)ws_bytes,
+                     (long long)Arena::bytes(batch));
+    return CASYNC_ERR_STATE;
+  }
+  CASYNC_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
+                     ((uintptr_t)ws % 256) == 0,
+                 "forward: pointers must be 16-B aligned (workspace 256-B)");
+  return CASYNC_OK;
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+int casync_abi_version(void) { return 1; }
+int casync_packed_count(void) { return (int)layout().items.size(); }
+const char* casync_packed_name(int i) {
+  return (i >= 0 && i < casync_packed_count()) ? layout().items[i].name.c_str() : nullptr;
+}
+int64_t casync_packed_offset(int i) { return (i >= 0 && i < casync_packed_count()) ? layout().items[i].offset : -1; }
+int64_t casync_packed_size(int i) { return (i >= 0 && i < casync_packed_count()) ? layout().items[i].size : -1; }
+int64_t casync_packed_total(void) { return layout().total; }
+int64_t casync_workspace_bytes(int batch) { return batch > 0 ? Arena::bytes(batch) : -1; }
+
+int casync_create(int device_id, casync_handle* out) {
+  CASYNC_REQUIRE(out, "create: null out");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    casync_set_error("create: no HIP device visible");
+    return CASYNC_ERR_NO_DEVICE;
+  }
+  CASYNC_REQUIRE(device_id >= 0 && device_id < n, "create: device %d of %d", device_id, n);
+  hipDeviceProp_t prop;
+  CASYNC_CHECK_HIP(hipGetDeviceProperties(&prop, device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    casync_set_error("create: device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+    return CASYNC_ERR_NO_DEVICE;
+  }
+  casync_engine* e = new casync_engine();
+  e->device = device_id;
+  *out = e;
+  return CASYNC_OK;
+}
+
+void casync_destroy(casync_handle h) {
+  if (!h) return;
+  if (h->owned) {
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->owned);
+  }
+  delete h;
+}
+
+int casync_load_weights_host(casync_handle h, const float* packed, int64_t n_floats) {
+  CASYNC_REQUIRE(h && packed, "load_weights: null");
+  CASYNC_REQUIRE(n_floats == layout().total, "load_weights: %lld floats, layout needs %lld",
+                 (long long)n_floats, (long long)layout().total);
+  CASYNC_CHECK_HIP(hipSetDevice(h->device));
+  if (!h->owned) CASYNC_CHECK_HIP(hipMalloc((void**)&h->owned, n_floats * sizeof(float)));
+  CASYNC_CHECK_HIP(hipMemcpy(h->owned, packed, n_floats * sizeof(float), hipMemcpyHostToDevice));
+  h->w = h->owned;
+  return CASYNC_OK;
+}
+
+int casync_load_weights_device(casync_handle h, const float* packed_dev, int64_t n_floats) {
+  CASYNC_REQUIRE(h && packed_dev, "load_weights_device: null");
+  CASYNC_REQUIRE(n_floats == layout().total, "load_weights_device: %lld floats, layout needs %lld",
+                 (long long)n_floats, (long long)layout().total);
+  CASYNC_REQUIRE(((uintptr_t)packed_dev % 256) == 0, "load_weights_device: buffer must be 256-B aligned");
+  h->w = packed_dev;
+  return CASYNC_OK;
+}
+
+int casync_forward(casync_handle h, const float* x, const float* a, float* out, int batch, void* ws,
+                   int64_t ws_bytes, casync_stream stream) {
+  int st = check_forward_args(h, x, a, out, batch, ws, ws_bytes);
+  if (st != CASYNC_OK) return st;
+  Runner r;
+  r.s = (hipStream_t)stream;
+  Plan p{*h, Arena(), r, batch};
+  p.ar.bind(ws, batch);
+  p.forward(x, a, out);
+  return r.status;
+}
+
+int casync_profile_forward(casync_handle h, const float* x, const float* a, float* out, int batch,
+                           void* ws, int64_t ws_bytes, casync_stream stream, casync_kernel_time* res,
+                           int cap) {
+  int st = check_forward_args(h, x, a, out, batch, ws, ws_bytes);
+  if (st != CASYNC_OK) return st;
+  CASYNC_REQUIRE(res && cap > 0, "profile_forward: null result buffer");
+  Runner r;
+  r.s = (hipStream_t)stream;
+  r.profile = true;
+  Plan p{*h, Arena(), r, batch};
+  p.ar.bind(ws, batch);
+  p.forward(x, a, out);
+  r.finish();
+  if (r.status != CASYNC_OK) return r.status;
+  const int n = (int)r.rec.size() < cap ? (int)r.rec.size() : cap;
+  for (int i = 0; i < n; ++i) res[i] = r.rec[i];
+  return n;
+}
+
+int64_t casync_tap(casync_handle h, const char* name, int batch, void* ws, float* dst, int64_t dst_floats,
+                   casync_stream stream) {
+  CASYNC_REQUIRE(h && name && ws && dst && batch > 0, "tap: bad args");
+  Arena ar;
+  ar.bind(ws, batch);
+  using A = Arena;
+  struct T { const char* n; const float* p; int ld, c, rows; };
+  const T taps[] = {
+      {"x1", ar[A::CAT4] + 32, 64, 32, 25600},  {"x2", ar[A::CAT3] + 64, 128, 64, 6400},
+      {"x3", ar[A::CAT2] + 128, 256, 128, 1600}, {"x4", ar[A::CAT1] + 256, 512, 256, 400},
+      {"x5", ar[A::CATA], 1024, 512, 100},      {"a", ar[A::CATA] + 512, 1024, 512, 100},
+      {"tx", ar[A::TX], 1024, 1024, 100},       {"kx", ar[A::KXF], 1024, 1024, 100},
+      {"att0", ar[A::OX0], 1024, 1024, 100},    {"att1", ar[A::OX1], 1024, 1024, 100},
+      {"att2", ar[A::OX2], 1024, 1024, 100},    {"att3", ar[A::OX3], 1024, 1024, 100},
+      {"fuse", ar[A::F], 256, 256, 100},        {"u1", ar[A::U1], 128, 128, 400},
+      {"u2", ar[A::U2], 64, 64, 1600},          {"u3", ar[A::U3], 32, 32, 6400},
+      {"u4", ar[A::U4], 32, 32, 25600},         {"audio_conv2", ar[A::AC2], 128, 128, 1024},
+      {"audio_conv3", ar[A::AC3], 256, 256, 256}, {"audio_conv4", ar[A::AC4], 256, 256, 256},
+      {"audio_conv5", ar[A::AC5], 512, 512, 100}};
+  for (const T& t : taps) {
+    if (strcmp(t.n, name) != 0) continue;
+    const int64_t per_frame = (int64_t)t.rows * t.c;
+    CASYNC_REQUIRE(dst_floats >= per_frame * batch, "tap %s: dst holds %lld floats, need %lld", name,
+                   (long long)dst_floats, (long long)(per_frame * batch));
+    CASYNC_CHECK_HIP(hipMemcpy2DAsync(dst, (size_t)t.c * 4, t.p, (size_t)t.ld * 4, (size_t)t.c * 4,
+                                      (size_t)t.rows * batch, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return per_frame;
+  }
+  casync_set_error("tap: unknown name %s", name);
+  return CASYNC_ERR_ARG;
+}
+
+// ---- single operators ------------------------------------------------------
+int casync_op_pw_gemm(const float* a, int lda, const float* w, const float* bias, float* c, int ldc,
+                      int m, int n, int k, int act, const float* pre_res, int ld_pre,
+                      const float* pre_scale, const float* post_res, int ld_post, const float* aff_s,
+                      const float* aff_t, casync_stream stream) {
+  GemmEpilogue e;
+  e.bias = bias;
+  e.act = act;
+  e.pre_res = pre_res;
+  e.ld_pre = ld_pre;
+  e.pre_scale = pre_scale;
+  e.post_res = post_res;
+  e.ld_post = ld_post;
+  e.aff_s = aff_s;
+  e.aff_t = aff_t;
+  CASYNC_REQUIRE(!aff_s || aff_t, "pw_gemm: aff_s without aff_t");
+  return launch_pw_gemm(a, lda, w, c, ldc, m, n, k, e, (hipStream_t)stream);
+}
+int casync_op_dw3x3(const float* in, const float* w, const float* bias, float* out, int batch, int h,
+                    int wdt, int c, int stride, casync_stream stream) {
+  return launch_dw3x3(in, w, bias, out, batch, h, wdt, c, stride, (hipStream_t)stream);
+}
+int casync_op_im2col3x3(const float* in, float* out, int batch, int h, int wdt, int c, int stride,
+                        int pad, casync_stream stream) {
+  return launch_im2col3x3(in, out, batch, h, wdt, c, stride, pad, (hipStream_t)stream);
+}
+int casync_op_upsample2x(const float* in, float* out, int ldc, int batch, int h, int wdt, int c,
+                         casync_stream stream) {
+  return launch_upsample2x(in, out, ldc, batch, h, wdt, c, (hipStream_t)stream);
+}
+int casync_op_cross_attention(const float* q, int ldq, const float* k, int ldk, const float* v,
+                              int ldv, const float* res, int ld_res, const float* gamma_dev,
+                              float* out, int ld_out, int batch, casync_stream stream) {
+  return launch_cross_attention(q, ldq, k, ldk, v, ldv, res, ld_res, gamma_dev, out, ld_out, batch,
+                                (hipStream_t)stream);
+}
+int casync_op_nchw_to_nhwc(const float* in, float* out, int batch, int c, int hw, casync_stream stream) {
+  return launch_nchw_to_nhwc(in, out, batch, c, hw, (hipStream_t)stream);
+}
+int casync_op_inc(const float* x_nchw, const float* packed_inc, float* out, int ldc, int batch,
+                  casync_stream stream) {
+  return launch_inc(x_nchw, packed_inc, out, ldc, batch, (hipStream_t)stream);
+}
+int casync_op_outc(const float* in, int ld_in, const float* w, const float* b, float* out_nchw,
+                   int batch, casync_stream stream) {
+  return launch_outc(in, ld_in, w, b, out_nchw, batch, (hipStream_t)stream);
+}
+
+}  // extern "C"

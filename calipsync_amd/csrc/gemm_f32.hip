@@ -1,0 +1,190 @@
+// 1x1 convolution / linear layer as an fp32 GEMM on the gfx950 matrix cores.
+//
+//   C[M,N] = epilogue( A[M,K] * W[N,K]^T )
+//
+// Replaces nn.Conv2d(k=1) / nn.Linear + eval BatchNorm (folded into W and bias on the
+// host) + LeakyReLU + residual adds of the reference (module/unet.py:17-20, 31-33, 38,
+// 201-204, 227-229, 256-259, 267-269, 323-326).  Activations are NHWC so a 1x1 conv over
+// B*H*W pixels IS a row-major GEMM with M = B*H*W; `lda`/`ldc` let a layer read from /
+// write into a channel slice of a wider (concat) buffer, which is how torch.cat
+// (module/unet.py:96, 323) disappears.
+//
+// Matrix core: v_mfma_f32_32x32x2_f32 (exact f32, k-ordered fma chain; 64 FLOP/clk/SIMD).
+// Operand maps (cdna guide §3): lane l supplies A[i = l&31][k = l>>5] and
+// B[k = l>>5][j = l&31]; C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// Both tiles sit in LDS as [row][k] with k contiguous (W is stored [N][K], PyTorch's own
+// conv-weight order), so one ds_read_b128 per operand feeds four MFMA k-steps: lane half
+// `kh` takes k = 8g+4kh .. +3 of every group of 8 -- any k permutation is legal as long
+// as A and B use the same one.  Row stride 36 floats (144 B) makes those b128 reads
+// bank-conflict free (16 distinct 16-B slots per lane group).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void pw_gemm_f32_kernel(const float* __restrict__ A, int lda,
+                                                          const float* __restrict__ W,
+                                                          float* __restrict__ C, int ldc, int M,
+                                                          int N, int K, int n_ntiles, int nwg,
+                                                          GemmEpilogue epi) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_PASS = BM / 32, B_PASS = BN / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                    // [2][BM][LDS_LD]
+  float* Bs = smem + 2 * BM * LDS_LD;  // [2][BN][LDS_LD]
+
+  // XCD-aware tile order: blocks b, b+8, ... share an XCD (round-robin dispatch); give each
+  // XCD a contiguous run of tiles so the N-tiles of one M-panel hit the same L2.  Bijective
+  // for any grid size.  Speed only -- never correctness.
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int mt = bid / n_ntiles, nt = bid - mt * n_ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int tid = threadIdx.x;
+  const int lrow = tid >> 3, lc4 = (tid & 7) * 4;  // staging: 8 lanes cover one 128-B row chunk
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int r32 = lane & 31, kh = lane >> 5;
+
+  f32x4 ra[A_PASS], rb[B_PASS];
+  const float* a_ptr[A_PASS];
+  const float* b_ptr[B_PASS];
+#pragma unroll
+  for (int p = 0; p < A_PASS; ++p) {
+    int row = m0 + lrow + 32 * p;
+    row = row < M ? row : M - 1;  // tail rows re-read the last valid row; never stored
+    a_ptr[p] = A + (size_t)row * lda + lc4;
+  }
+#pragma unroll
+  for (int p = 0; p < B_PASS; ++p) b_ptr[p] = W + (size_t)(n0 + lrow + 32 * p) * K + lc4;
+
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int p = 0; p < A_PASS; ++p) ra[p] = *reinterpret_cast<const f32x4*>(a_ptr[p] + kt * BK);
+#pragma unroll
+    for (int p = 0; p < B_PASS; ++p) rb[p] = *reinterpret_cast<const f32x4*>(b_ptr[p] + kt * BK);
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < A_PASS; ++p)
+      *reinterpret_cast<f32x4*>(As + (buf * BM + lrow + 32 * p) * LDS_LD + lc4) = ra[p];
+#pragma unroll
+    for (int p = 0; p < B_PASS; ++p)
+      *reinterpret_cast<f32x4*>(Bs + (buf * BN + lrow + 32 * p) * LDS_LD + lc4) = rb[p];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = K / BK;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);  // in flight under the MFMAs below
+    const float* a_base = As + (buf * BM + wm * (BM / WM) + r32) * LDS_LD + 4 * kh;
+    const float* b_base = Bs + (buf * BN + wn * (BN / WN) + r32) * LDS_LD + 4 * kh;
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      f32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * LDS_LD + 8 * g);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * LDS_LD + 8 * g);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns one output column per N sub-tile, 16 rows per M sub-tile ----
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (BN / WN) + j * 32 + r32;
+    const float bias = epi.bias ? epi.bias[n] : 0.f;
+    const float pscale = epi.pre_scale ? epi.pre_scale[n] : 1.f;
+    const float as = epi.aff_s ? epi.aff_s[n] : 1.f;
+    const float at = epi.aff_s ? epi.aff_t[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mbase = m0 + wm * (BM / WM) + i * 32 + 4 * kh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2);
+        if (m < M) {
+          float v = acc[i][j][r] + bias;
+          if (epi.pre_res) v += pscale * epi.pre_res[(size_t)m * epi.ld_pre + n];
+          if (epi.act) v = lrelu(v);
+          if (epi.post_res) v += epi.post_res[(size_t)m * epi.ld_post + n];
+          if (epi.aff_s && !epi.aff_on_acc) v = lrelu(v * as + at);
+          C[(size_t)m * ldc + n] = v;
+          if (epi.acc_out) {
+            float s = epi.acc_in[(size_t)m * epi.ld_acc + n] + v;
+            if (epi.aff_s && epi.aff_on_acc) s = lrelu(s * as + at);
+            epi.acc_out[(size_t)m * epi.ld_acc + n] = s;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg(const float* a, int lda, const float* w, float* c, int ldc, int m, int n, int k,
+               const GemmEpilogue& epi, hipStream_t stream) {
+  constexpr size_t lds = 2ull * (BM + BN) * LDS_LD * sizeof(float);
+  static bool attr_set = false;
+  auto kern = pw_gemm_f32_kernel<BM, BN, WM, WN>;
+  if (!attr_set) {
+    CASYNC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int n_mtiles = (m + BM - 1) / BM, n_ntiles = n / BN;
+  const long long nwg = (long long)n_mtiles * n_ntiles;
+  CASYNC_REQUIRE(nwg < (1ll << 31), "gemm grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, a, lda, w, c, ldc, m, n, k,
+                     n_ntiles, (int)nwg, epi);
+  CASYNC_CHECK_HIP(hipGetLastError());
+  return CASYNC_OK;
+}
+
+}  // namespace
+
+int launch_pw_gemm(const float* a, int lda, const float* w, float* c, int ldc, int m, int n, int k,
+                   const GemmEpilogue& epi, hipStream_t stream) {
+  CASYNC_REQUIRE(a && w && c, "pw_gemm: null pointer");
+  CASYNC_REQUIRE(m > 0 && n > 0 && k > 0, "pw_gemm: empty problem m=%d n=%d k=%d", m, n, k);
+  CASYNC_REQUIRE(k % BK == 0, "pw_gemm: K=%d must be a multiple of %d", k, BK);
+  CASYNC_REQUIRE(n % 32 == 0, "pw_gemm: N=%d must be a multiple of 32", n);
+  CASYNC_REQUIRE(lda % 4 == 0 && lda >= k, "pw_gemm: lda=%d (K=%d) must be >= K and a multiple of 4", lda, k);
+  CASYNC_REQUIRE(ldc >= n, "pw_gemm: ldc=%d < N=%d", ldc, n);
+  CASYNC_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)w % 16) == 0, "pw_gemm: A/W must be 16-B aligned");
+  CASYNC_REQUIRE(!epi.acc_out || epi.acc_in, "pw_gemm: acc_out without acc_in");
+  if (n % 128 == 0) return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream);
+  if (n % 64 == 0) return launch_cfg<128, 64, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream);
+  return launch_cfg<128, 32, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream);
+}

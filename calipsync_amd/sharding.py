@@ -1,0 +1,61 @@
+"""Multi-GPU plumbing for the frame loop: one process per GPU, frames sharded, weights
+broadcast once.
+
+The reference is single-device (``cuda:0`` everywhere: inference.py:18,
+frame_synthesizer/infer_api.py:14) and has no distributed code.  Frames are independent in
+eval mode, so the only exchange this path needs is ONE broadcast of the
+packed, BN-folded weight buffer (~79 MB fp32) from rank 0 at start-up -- over RCCL/xGMI on
+the GPU box (backend "nccl"), over gloo in the CPU tests.  No steady-state collective.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous slice [start, start+count) of `total` frames owned by `rank`.
+
+    The first ``total % world`` ranks take one extra frame; empty shards are legal."""
+    if world <= 0 or not (0 <= rank < world) or total < 0:
+        raise ValueError(f"bad shard request total={total} rank={rank} world={world}")
+    base, extra = divmod(total, world)
+    start = rank * base + min(rank, extra)
+    return start, base + (1 if rank < extra else 0)
+
+
+def shard_frames(x: torch.Tensor, audio: torch.Tensor, rank: int, world: int):
+    """This rank's slice of a global batch (views, no copy)."""
+    s, n = shard_range(x.shape[0], rank, world)
+    return x[s:s + n], audio[s:s + n]
+
+
+def packed_total() -> int:
+    from . import _lib
+    return int(_lib.load().casync_packed_total())
+
+
+def broadcast_packed_weights(model_on_src, device: torch.device, src: int = 0,
+                             group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """Rank `src` folds + packs its model's weights; everyone receives the flat buffer.
+
+    ``model_on_src`` is the calipsync_amd.unet.Model holding the checkpoint on rank `src`
+    (ignored -- may be None -- elsewhere).  Returns a contiguous fp32 tensor on `device`
+    that ``Model.adopt_packed`` can take without another copy."""
+    n = packed_total()
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    rank = dist.get_rank(group) if distributed else src
+    if rank == src:
+        if model_on_src is None:
+            raise ValueError("the source rank must pass its model")
+        host = model_on_src.packed_weights_host()
+        assert host.shape == (n,) and host.dtype == np.float32
+        buf = torch.from_numpy(host).to(device)
+    else:
+        buf = torch.empty(n, dtype=torch.float32, device=device)
+    if distributed:
+        dist.broadcast(buf, src=src, group=group)
+    return buf

@@ -1,0 +1,144 @@
+/*
+ * casync_hip.h -- C ABI of libcasync_hip.so, the MI355X (gfx950) engine for the
+ * CASync lip-sync U-Net per-frame inference forward.
+ *
+ * The reference has no FFI: its boundary for this path is the Python call
+ *     predictions = self.net(batch_tensor, hubert_tensor)
+ * (reference image_infer_v1/tools/frame_synthesizer/infer_api.py:259-260) on an
+ * nn.Module built by Model(6, "hubert") / load_state_dict / eval()
+ * (infer_api.py:41-43; module/unet.py:273-345).  This library is what a
+ * binding for that call binds: plain pointers and sizes, explicit stream, int
+ * status codes, no C++ exceptions, no torch types.  calipsync_amd/unet.py is
+ * the ctypes host that keeps the reference's Model.forward(x, audio_feat)
+ * signature on top of it (INTEGRATION.md shows the stub).
+ *
+ * All device pointers are fp32, 16-byte aligned.  Tensors at the boundary are
+ * the reference's own layouts (NCHW, contiguous); internally the engine works
+ * in NHWC.  A handle is bound to one device and is not thread-safe: one
+ * caller / one stream at a time (the reference has one caller at a time,
+ * infer_api.py:259 under inference.py:80 or a worker thread).
+ */
+#ifndef CASYNC_HIP_H
+#define CASYNC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct casync_engine* casync_handle;
+typedef void* casync_stream;          /* a hipStream_t (NULL = default stream) */
+
+/* status codes (0 = ok, negative = error; never throws) */
+enum {
+  CASYNC_OK = 0,
+  CASYNC_ERR_ARG = -1,        /* null pointer / bad size / unsupported shape   */
+  CASYNC_ERR_HIP = -2,        /* a HIP runtime call failed (see last_error)    */
+  CASYNC_ERR_STATE = -3,      /* weights not loaded / workspace too small      */
+  CASYNC_ERR_NO_DEVICE = -4   /* no gfx950 device visible                      */
+};
+
+/* ---- introspection (callable without a GPU) --------------------------- */
+int         casync_abi_version(void);
+const char* casync_last_error(void);           /* thread-local message         */
+
+/* Packed-weight layout.  The host folds eval-mode BatchNorm into the conv /
+ * linear weights (replaces nn.BatchNorm2d/1d + bias adds, module/unet.py:18,
+ * 28,32,163,168,174,228,230,260,301,310,311) and writes each folded tensor at
+ * the offset this table names.  Offsets/sizes are in floats.               */
+int         casync_packed_count(void);
+const char* casync_packed_name(int i);
+int64_t     casync_packed_offset(int i);
+int64_t     casync_packed_size(int i);
+int64_t     casync_packed_total(void);          /* floats in the whole buffer  */
+
+/* Workspace (activations, NHWC fp32) needed for a batch of B frames.        */
+int64_t     casync_workspace_bytes(int batch);
+
+/* ---- engine life cycle ------------------------------------------------- */
+/* Replaces Model(6,"hubert").to(device) (infer_api.py:41).                   */
+int  casync_create(int device_id, casync_handle* out);
+void casync_destroy(casync_handle h);
+
+/* Replaces net.load_state_dict(...) (infer_api.py:42): the packed, BN-folded
+ * buffer of casync_packed_total() floats.  _host copies from host memory into
+ * an engine-owned device buffer; _device adopts a caller-owned device buffer
+ * (e.g. the tensor an RCCL broadcast just filled) without copying -- the
+ * caller keeps it alive for the life of the handle.                          */
+int  casync_load_weights_host(casync_handle h, const float* packed, int64_t n_floats);
+int  casync_load_weights_device(casync_handle h, const float* packed_dev, int64_t n_floats);
+
+/* Replaces Model.forward(x, audio_feat) (module/unet.py:314-345).
+ *   x_dev     [B,6,160,160]  NCHW fp32   (reference crop ch0-2, masked crop ch3-5)
+ *   audio_dev [B,32,32,32]   NCHW fp32   (HuBERT window)
+ *   out_dev   [B,3,160,160]  NCHW fp32   in (0,1)
+ * Enqueues on `stream`, no host synchronisation, no allocation.             */
+int  casync_forward(casync_handle h, const float* x_dev, const float* audio_dev,
+                    float* out_dev, int batch, void* workspace_dev,
+                    int64_t workspace_bytes, casync_stream stream);
+
+/* Debug taps: copy a named NHWC intermediate of the LAST forward (same batch,
+ * same workspace) into dst_dev; returns its per-frame float count or <0.
+ * Names: x1 x2 x3 x4 x5 a tx kx fuse u1 u2 u3 u4 att0..att3 audio_conv2..5   */
+int64_t casync_tap(casync_handle h, const char* name, int batch, void* workspace_dev,
+                   float* dst_dev, int64_t dst_floats, casync_stream stream);
+
+/* Per-kernel timing of one forward (HIP events around every launch on
+ * `stream`; synchronises).  Writes up to `cap` entries; returns the count.  */
+typedef struct {
+  char  name[48];
+  float ms;
+  double flops;       /* algorithmic flops of this launch                   */
+  double bytes;       /* algorithmic bytes (inputs read once + outputs)     */
+} casync_kernel_time;
+int  casync_profile_forward(casync_handle h, const float* x_dev, const float* audio_dev,
+                            float* out_dev, int batch, void* workspace_dev,
+                            int64_t workspace_bytes, casync_stream stream,
+                            casync_kernel_time* out, int cap);
+
+/* ---- single operators (used by the parity tests and micro-benchmarks) ---- */
+/* 1x1 conv / linear as GEMM on NHWC rows: C[M,N] = epi(A[M,K] * W[N,K]^T).
+ * Replaces nn.Conv2d(k=1)/nn.Linear + folded BN + LeakyReLU (+ residual)
+ * (module/unet.py:17-20,31-33,201-204,227-229,256-259).
+ * epilogue: v = acc + bias[n]; v += pre_scale[n]*pre_res[m,n]; v = lrelu(v) if
+ * act; v += post_res[m,n]; v = lrelu(v*aff_s[n]+aff_t[n]) if aff_s.         */
+int casync_op_pw_gemm(const float* a, int lda, const float* w, const float* bias,
+                      float* c, int ldc, int m, int n, int k, int act,
+                      const float* pre_res, int ld_pre, const float* pre_scale,
+                      const float* post_res, int ld_post,
+                      const float* aff_s, const float* aff_t, casync_stream stream);
+/* Depthwise 3x3, pad 1, stride 1|2, + bias + LeakyReLU on NHWC.
+ * Replaces nn.Conv2d(groups=C,k=3)+BN+LeakyReLU (module/unet.py:21-30).
+ * w is tap-major [9][C].                                                    */
+int casync_op_dw3x3(const float* in, const float* w, const float* bias, float* out,
+                    int batch, int h, int wdt, int c, int stride, casync_stream stream);
+/* im2col for the two dense 3x3 stride-2 convs (module/unet.py:161-168):
+ * out[B*Ho*Wo][9*C], column order (ky,kx,c).                                */
+int casync_op_im2col3x3(const float* in, float* out, int batch, int h, int wdt, int c,
+                        int stride, int pad, casync_stream stream);
+/* Bilinear x2, align_corners=True (module/unet.py:86-87,91), NHWC, writing
+ * into a wider row (ldc) so the concat with the skip is free.               */
+int casync_op_upsample2x(const float* in, float* out, int ldc, int batch, int h, int wdt,
+                         int c, casync_stream stream);
+/* Cross attention core (module/unet.py:212-217): per frame
+ * out = gamma * (softmax_j(Q K^T) V) + res, 100 face x 100 audio positions.  */
+int casync_op_cross_attention(const float* q, int ldq, const float* k, int ldk,
+                              const float* v, int ldv, const float* res, int ld_res,
+                              const float* gamma_dev, float* out, int ld_out,
+                              int batch, casync_stream stream);
+/* NCHW <-> NHWC helpers */
+int casync_op_nchw_to_nhwc(const float* in, float* out, int batch, int c, int hw,
+                           casync_stream stream);
+/* inc block straight from the NCHW face crop (module/unet.py:58-67,290)      */
+int casync_op_inc(const float* x_nchw, const float* packed_inc, float* out, int ldc,
+                  int batch, casync_stream stream);
+/* OutConv + outc_bn + sigmoid -> NCHW (module/unet.py:100-106,342-344)       */
+int casync_op_outc(const float* in, int ld_in, const float* w, const float* b,
+                   float* out_nchw, int batch, casync_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CASYNC_HIP_H */

@@ -1,0 +1,104 @@
+"""C-ABI library: loads without a GPU, exports every declared symbol, and agrees with the
+Python packer on the packed-weight layout.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from calipsync_amd import _lib, arch, pack
+from calipsync_amd.unet import Model
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from calipsync_amd import build
+    build.build()            # cross-compiles for gfx950 without a GPU
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    header = open(os.path.join(REPO, "include", "casync_hip.h")).read()
+    declared = set(re.findall(r"\b(casync_[a-z0-9_]+)\s*\(", header))
+    declared -= {"casync_engine"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_abi_version_and_layout(lib):
+    assert lib.casync_abi_version() == 1
+    items, total = _lib.packed_layout()
+    names = [n for n, _, _ in items]
+    assert len(names) == len(set(names))
+    end = 0
+    for name, off, size in items:
+        assert off % 64 == 0 and off >= end and size > 0, name
+        end = off + size
+    assert total >= end and total * 4 < 90e6       # ~79 MB of folded fp32 weights
+
+
+def test_packer_fills_the_engine_layout(lib, recipe_sd):
+    buf = pack.pack(recipe_sd)
+    items, total = _lib.packed_layout()
+    assert buf.shape == (total,) and buf.dtype == np.float32
+    used = sum(s for _, _, s in items)
+    # folded weights == conv/linear weights + one bias/scale vector per layer
+    assert used > 19_700_000
+    off = dict((n, (o, s)) for n, o, s in items)
+    o, s = off["attention_blocks.2.gamma"]
+    assert buf[o] == np.float32(0.5) and s == 1
+
+
+def test_bn_folding_is_exact_on_one_layer(recipe_sd):
+    """Folded PW1 of down1.ir0 reproduces conv+BN of the oracle on random rows."""
+    from oracle import unet_oracle
+    import torch.nn.functional as F
+    sd = unet_oracle.to_torch(recipe_sd)
+    f = pack.fold(recipe_sd)
+    p = "down1.maxpool_conv.0.double_conv.0"
+    x = torch.randn(1, 32, 5, 7)
+    ref = unet_oracle._bn(sd, f"{p}.conv.1", F.conv2d(x, sd[f"{p}.conv.0.weight"]))
+    w = torch.from_numpy(f[f"{p}.pw1.w"].astype(np.float32))
+    b = torch.from_numpy(f[f"{p}.pw1.b"].astype(np.float32))
+    got = torch.einsum("nk,bkhw->bnhw", w, x) + b[None, :, None, None]
+    assert (got - ref).abs().max() < 2e-6
+
+
+def test_workspace_bytes_scale_with_batch(lib):
+    one, many = lib.casync_workspace_bytes(1), lib.casync_workspace_bytes(64)
+    assert 40e6 < one < 80e6 and abs(many / one - 64) < 0.01
+    assert lib.casync_workspace_bytes(0) < 0
+
+
+def test_model_has_reference_checkpoint_format(recipe_sd):
+    m = Model(6, "hubert")
+    sd = m.state_dict()
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == [(k, s) for k, s, _, _ in arch.manifest()]
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe_sd.items()})   # strict
+    bad = dict(recipe_sd)
+    bad.pop("bn_kx.weight")
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in bad.items()})
+    with pytest.raises(NotImplementedError):
+        Model(6, "wenet")
+
+
+def test_no_cpu_fallback():
+    m = Model(6, "hubert")
+    with pytest.raises(RuntimeError, match="ROCm device only"):
+        m(torch.zeros(1, 6, 160, 160), torch.zeros(1, 32, 32, 32))
+    with pytest.raises(RuntimeError, match=r"\[B,6,160,160\]"):
+        m(torch.zeros(1, 3, 160, 160), torch.zeros(1, 32, 32, 32))
+
+
+def test_create_without_gpu_reports_no_device(lib):
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    h = ctypes.c_void_p()
+    assert lib.casync_create(0, ctypes.byref(h)) < 0
+    assert b"device" in lib.casync_last_error()

@@ -1,0 +1,103 @@
+"""-m gpu: the whole HIP forward through the drop-in Model vs (a) the golden vectors made
+by the reference itself and (b) the CPU oracle on fresh seeded inputs.
+
+Bar (BASELINE.json north_star): |delta| < 1e-3 per pixel, fp32."""
+import numpy as np
+import pytest
+import torch
+
+from calipsync_amd import recipe
+from calipsync_amd.unet import Model
+from conftest import sample_indices
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3          # north-star bar
+EXPECT = 5e-5       # what fp32 MFMA + BN folding actually delivers; regressions show here first
+
+
+@pytest.fixture(scope="module")
+def net(recipe_sd):
+    m = Model(6, "hubert").to("cuda:0")
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe_sd.items()})
+    return m.eval()
+
+
+def test_golden_output(net, golden):
+    x, a = recipe.make_inputs(2)
+    out = net(torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda())
+    assert out.shape == (2, 3, 160, 160) and out.dtype == torch.float32 and out.is_cuda
+    d = np.abs(out.cpu().numpy() - golden["out.full"]).max()
+    print("max|d| vs reference golden:", d)
+    assert d < TOL and d < EXPECT
+
+
+TAPS = ["x1", "x2", "x3", "x4", "x5", "audio_conv2", "audio_conv3", "audio_conv4", "audio_conv5", "a",
+        "tx", "att0", "att1", "att2", "att3", "kx", "fuse", "u1", "u2", "u3", "u4"]
+
+
+@pytest.mark.parametrize("name", TAPS)
+def test_golden_intermediates(net, golden, name):
+    x, a = recipe.make_inputs(2)
+    net(torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda())
+    t = net.tap(name, 2).cpu().numpy()
+    assert tuple(golden[f"{name}.shape"]) == t.shape
+    if f"{name}.full" in golden:
+        ref, got = golden[f"{name}.full"].reshape(-1), t.reshape(-1)
+    else:
+        ref, got = golden[f"{name}.samples"], t.reshape(-1)[sample_indices(t.size)]
+    scale = max(1.0, float(np.abs(ref).max()))
+    d = np.abs(got - ref).max() / scale
+    assert d < 2e-5, (name, d)
+
+
+@pytest.mark.parametrize("batch", [1, 3, 64])
+def test_against_oracle(net, recipe_sd, batch):
+    """configs[0]/[1] of BASELINE.json: B=1 plumbing and B=64 fp32 vs the CPU path."""
+    from oracle import unet_oracle
+    torch.set_num_threads(16)
+    sd = unet_oracle.to_torch(recipe_sd)
+    x, a = recipe.make_inputs_range(100, batch)
+    xt, at = torch.from_numpy(x), torch.from_numpy(a)
+    ref = unet_oracle.forward(sd, xt, at)
+    out = net(xt.cuda(), at.cuda()).cpu()
+    d = float((out - ref).abs().max())
+    print(f"B={batch} max|d| vs oracle: {d:.3e}")
+    assert d < TOL and d < EXPECT
+
+
+def test_frames_independent_and_batch_invariant(net):
+    """A frame's output must not depend on its neighbours or its position in the batch."""
+    x, a = recipe.make_inputs(5)
+    xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
+    full = net(xt, at)
+    part = net(xt[3:4].contiguous(), at[3:4].contiguous())
+    assert torch.equal(full[3:4], part)              # bitwise: same kernels, same order per frame
+
+
+def test_audio_matters(net):
+    x, a = recipe.make_inputs(2)
+    xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
+    d = (net(xt, at) - net(xt, at.flip(0).contiguous())).abs().max()
+    assert d > 1e-2
+
+
+def test_reload_and_default_init(net, recipe_sd):
+    """load_state_dict re-packs; a default-init model (gamma=0) also runs and stays in (0,1)."""
+    m = Model(6, "hubert").to("cuda:0")
+    x, a = recipe.make_inputs(1)
+    out0 = m(torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda())
+    assert torch.isfinite(out0).all() and out0.min() > 0 and out0.max() < 1
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe_sd.items()})
+    out1 = m(torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda())
+    assert torch.equal(out1, net(torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()))
+
+
+def test_empty_and_bad_inputs(net):
+    e = net(torch.zeros(0, 6, 160, 160).cuda(), torch.zeros(0, 32, 32, 32).cuda())
+    assert e.shape == (0, 3, 160, 160)
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 6, 160, 160), torch.zeros(1, 32, 32, 32).cuda())      # CPU input
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(2, 6, 160, 160).cuda(), torch.zeros(1, 32, 32, 32).cuda())
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 6, 160, 160).cuda().half(), torch.zeros(1, 32, 32, 32).cuda())

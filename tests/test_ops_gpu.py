@@ -1,0 +1,184 @@
+"""-m gpu: every HIP operator through the C ABI vs a plain PyTorch fp32 reference of the
+same op (CPU).  Tolerance: fp32 rounding only (the whole-net bar is 1e-3; single ops sit
+at ~1e-6 relative)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from calipsync_amd import _lib, pack
+from gpu_util import dev, nchw, nhwc, ok, ptr, stream
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(got, ref):
+    return float((got - ref).abs().max() / max(1e-6, float(ref.abs().max())))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _lib.load()
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (1000, 64, 64), (6400, 1024, 512), (257, 32, 128),
+                                   (100, 2304, 512), (300, 256, 1152), (25600, 32, 64), (5, 64, 512)])
+def test_pw_gemm_plain(lib, m, n, k):
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g)
+    ref = F.leaky_relu(a.double() @ w.double().T + b.double(), 0.01).float()
+    ad, wd, bd = a.to(dev()), w.to(dev()), b.to(dev())
+    c = torch.empty(m, n, device=dev())
+    ok(lib.casync_op_pw_gemm(ptr(ad), k, ptr(wd), ptr(bd), ptr(c), n, m, n, k, 1, 0, 0, 0, 0, 0, 0, 0, stream()))
+    assert rel_err(c.cpu(), ref) < 2e-6
+
+
+def test_pw_gemm_epilogue_and_strides(lib):
+    """lda/ldc slices of wider buffers + pre-residual (scaled) + post-residual + affine."""
+    g = torch.Generator().manual_seed(3)
+    m, n, k, lda, ldc = 777, 128, 64, 96, 160
+    abuf = torch.randn(m, lda, generator=g)
+    w = torch.randn(n, k, generator=g) / 8
+    bias, ps, s2, t2 = (torch.randn(n, generator=g) for _ in range(4))
+    pre, post = torch.randn(m, n, generator=g), torch.randn(m, n + 32, generator=g)
+    a = abuf[:, 32:32 + k]
+    v = a.double() @ w.double().T + bias.double() + ps.double() * pre.double()
+    v = F.leaky_relu(v, 0.01) + post[:, :n].double()
+    ref = F.leaky_relu(v * s2.double() + t2.double(), 0.01).float()
+    D = lambda t: t.to(dev())
+    abuf_d, cbuf = D(abuf), torch.full((m, ldc), -7.0, device=dev())
+    wd, bd, psd, s2d, t2d, pred, postd = map(D, (w, bias, ps, s2, t2, pre, post))
+    ok(lib.casync_op_pw_gemm(abuf_d.data_ptr() + 32 * 4, lda, ptr(wd), ptr(bd), cbuf.data_ptr() + 16 * 4,
+                             ldc, m, n, k, 1, ptr(pred), n, ptr(psd), ptr(postd), n + 32, ptr(s2d),
+                             ptr(t2d), stream()))
+    out = cbuf.cpu()
+    assert rel_err(out[:, 16:16 + n], ref) < 2e-6
+    assert (out[:, :16] == -7).all() and (out[:, 16 + n:] == -7).all()     # nothing outside the slice
+
+
+def test_pw_gemm_rejects_bad_shapes(lib):
+    a = torch.zeros(64, 48, device=dev())
+    assert lib.casync_op_pw_gemm(ptr(a), 48, ptr(a), 0, ptr(a), 48, 64, 48, 48, 0, 0, 0, 0, 0, 0, 0, 0, stream()) < 0
+    assert b"multiple" in lib.casync_last_error()
+
+
+@pytest.mark.parametrize("b,h,w,c,stride", [(2, 160, 160, 12, 1), (3, 80, 80, 64, 2), (2, 10, 10, 2048, 1),
+                                            (1, 21, 13, 8, 2), (2, 32, 32, 128, 1), (1, 7, 9, 4, 1)])
+def test_dw3x3(lib, b, h, w, c, stride):
+    g = torch.Generator().manual_seed(c + h)
+    x = torch.randn(b, c, h, w, generator=g)
+    wt = torch.randn(c, 1, 3, 3, generator=g) / 3
+    bias = torch.randn(c, generator=g)
+    ref = F.leaky_relu(F.conv2d(x, wt, bias, stride, 1, 1, c), 0.01)
+    wp = wt.reshape(c, 9).T.contiguous().to(dev())       # tap-major [9][C]
+    xd, bd = nhwc(x), bias.to(dev())
+    out = torch.empty(b, ref.shape[2], ref.shape[3], c, device=dev())
+    ok(lib.casync_op_dw3x3(ptr(xd), ptr(wp), ptr(bd), ptr(out), b, h, w, c, stride, stream()))
+    assert rel_err(nchw(out), ref) < 2e-6
+
+
+@pytest.mark.parametrize("h,c,stride,padv,cout", [(32, 128, 2, 1, 256), (16, 256, 2, 3, 512)])
+def test_dense3x3_via_im2col(lib, h, c, stride, padv, cout):
+    """conv3 (pad 1) and conv5 (pad 3: 16 -> 10) of the audio encoder."""
+    g = torch.Generator().manual_seed(h)
+    b = 2
+    x = torch.randn(b, c, h, h, generator=g)
+    wt = torch.randn(cout, c, 3, 3, generator=g) / (3 * c ** 0.5)
+    bias = torch.randn(cout, generator=g)
+    ref = F.leaky_relu(F.conv2d(x, wt, bias, stride, padv), 0.01)
+    ho = ref.shape[2]
+    assert ho == (10 if padv == 3 else 16)
+    xd = nhwc(x)
+    col = torch.empty(b * ho * ho, 9 * c, device=dev())
+    ok(lib.casync_op_im2col3x3(ptr(xd), ptr(col), b, h, h, c, stride, padv, stream()))
+    wp = wt.permute(0, 2, 3, 1).reshape(cout, 9 * c).contiguous().to(dev())
+    out = torch.empty(b * ho * ho, cout, device=dev())
+    bd = bias.to(dev())
+    ok(lib.casync_op_pw_gemm(ptr(col), 9 * c, ptr(wp), ptr(bd), ptr(out), cout, b * ho * ho, cout, 9 * c, 1,
+                             0, 0, 0, 0, 0, 0, 0, stream()))
+    assert rel_err(nchw(out.view(b, ho, ho, cout)), ref) < 3e-6
+
+
+@pytest.mark.parametrize("h,c", [(10, 256), (20, 128), (40, 64), (80, 32), (3, 4)])
+def test_upsample2x_align_corners(lib, h, c):
+    x = torch.randn(2, c, h, h, generator=torch.Generator().manual_seed(h))
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    ldc = 2 * c
+    out = torch.full((2, 2 * h, 2 * h, ldc), 5.0, device=dev())
+    ok(lib.casync_op_upsample2x(ptr(nhwc(x)), ptr(out), ldc, 2, h, h, c, stream()))
+    o = out.cpu()
+    assert (o[..., c:] == 5).all()                                   # skip half untouched
+    assert (o[..., :c].permute(0, 3, 1, 2) - ref).abs().max() < 1e-5
+
+
+def test_cross_attention(lib):
+    """module/unet.py:212-217 with gamma != 0: unscaled scores, softmax over audio positions."""
+    g = torch.Generator().manual_seed(11)
+    b = 3
+    q = torch.randn(b, 100, 64, generator=g) * 0.5
+    kv = torch.randn(b, 100, 2304, generator=g) * 0.5
+    res = torch.randn(b, 100, 512, generator=g)
+    gamma = torch.tensor([0.37])
+    k, v = kv[:, :, 576:640], kv[:, :, 640:1152]                     # block 1's slice of the KV rows
+    att = torch.softmax(q.double() @ k.double().transpose(1, 2), -1)
+    ref = (gamma.double() * (att @ v.double()) + res.double()).float()
+    qd, kvd, rd, gd = q.to(dev()), kv.to(dev()), res.to(dev()), gamma.to(dev())
+    out = torch.empty(b, 100, 512, device=dev())
+    ok(lib.casync_op_cross_attention(ptr(qd), 64, kvd.data_ptr() + 576 * 4, 2304, kvd.data_ptr() + 640 * 4, 2304,
+                                     ptr(rd), 512, ptr(gd), ptr(out), 512, b, stream()))
+    assert rel_err(out.cpu(), ref) < 3e-6
+
+
+def test_cross_attention_peaked_softmax(lib):
+    """Large-magnitude scores (one-hot rows) must not overflow: max-subtracted softmax."""
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(1, 100, 64, generator=g) * 6
+    k = torch.randn(1, 100, 64, generator=g) * 6
+    v = torch.randn(1, 100, 512, generator=g)
+    res = torch.zeros(1, 100, 512)
+    att = torch.softmax(q.double() @ k.double().transpose(1, 2), -1)
+    ref = (att @ v.double()).float()
+    out = torch.empty(1, 100, 512, device=dev())
+    gd = torch.ones(1, device=dev())
+    qd, kd, vd, rd = (t.to(dev()) for t in (q, k, v, res))
+    ok(lib.casync_op_cross_attention(ptr(qd), 64, ptr(kd), 64, ptr(vd), 512, ptr(rd), 512, ptr(gd), ptr(out), 512, 1, stream()))
+    assert torch.isfinite(out).all() and rel_err(out.cpu(), ref) < 1e-4
+
+
+def test_nchw_to_nhwc(lib):
+    x = torch.randn(3, 32, 32, 32)
+    out = torch.empty(3, 1024, 32, device=dev())
+    xd = x.to(dev())
+    ok(lib.casync_op_nchw_to_nhwc(ptr(xd), ptr(out), 3, 32, 1024, stream()))
+    assert torch.equal(out.cpu(), x.reshape(3, 32, 1024).transpose(1, 2))
+
+
+def test_inc_block(lib, recipe_sd, golden):
+    """Whole `inc` inverted residual from the NCHW crop vs the oracle's module."""
+    from calipsync_amd import recipe
+    from oracle import unet_oracle
+    sd = unet_oracle.to_torch(recipe_sd)
+    x, _ = recipe.make_inputs(2)
+    xt = torch.from_numpy(x)
+    ref = unet_oracle.inverted_residual(sd, "inc.inconv.0", xt, 1, False)
+    packed = torch.from_numpy(pack.fold(recipe_sd)["inc.inconv.0.fused"].astype(np.float32)).to(dev())
+    out = torch.full((2, 160, 160, 64), 9.0, device=dev())
+    xd = xt.to(dev())
+    ok(lib.casync_op_inc(ptr(xd), ptr(packed), out.data_ptr() + 32 * 4, 64, 2, stream()))
+    o = out.cpu()
+    assert (o[..., :32] == 9).all()
+    assert (o[..., 32:].permute(0, 3, 1, 2) - ref).abs().max() < 1e-5
+
+
+def test_outc_head(lib):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 32, 160, 160, generator=g)
+    w = torch.randn(3, 32, generator=g) / 4
+    b = torch.randn(3, generator=g)
+    ref = torch.sigmoid(torch.einsum("oc,bchw->bohw", w, x) + b[None, :, None, None])
+    out = torch.empty(2, 3, 160, 160, device=dev())
+    wd, bd = w.to(dev()), b.to(dev())
+    ok(lib.casync_op_outc(ptr(nhwc(x)), 32, ptr(wd), ptr(bd), ptr(out), 2, stream()))
+    assert (out.cpu() - ref).abs().max() < 2e-6

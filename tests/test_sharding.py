@@ -1,0 +1,67 @@
+"""Frame sharding + the one-time weight broadcast, world_size 2 over gloo on the CPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from calipsync_amd.sharding import shard_range
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 64, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            pos = 0
+            for s, n in spans:
+                assert s == pos and n >= 0
+                pos += n
+            assert pos == total
+            assert max(n for _, n in spans) - min(n for _, n in spans) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from calipsync_amd import recipe
+        from calipsync_amd.sharding import broadcast_packed_weights, shard_frames
+        from calipsync_amd.unet import Model
+        net = None
+        if rank == 0:
+            net = Model(6, "hubert")
+            net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe.make_state_dict().items()})
+        buf = broadcast_packed_weights(net, torch.device("cpu"))
+        # every rank must now hold rank 0's folded weights bit for bit
+        digest = torch.tensor([float(buf.double().sum()), float(buf.double().abs().sum()), float(buf.numel())],
+                              dtype=torch.float64)
+        gathered = [torch.zeros_like(digest) for _ in range(world)]
+        dist.all_gather(gathered, digest)
+        x = torch.arange(5 * 6, dtype=torch.float32).reshape(5, 6)
+        xs, _ = shard_frames(x, x, rank, world)
+        q.put((rank, [g.tolist() for g in gathered], xs[:, 0].tolist(), bool((buf != 0).any())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_weight_broadcast_and_frame_shards_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, g0, f0, nz0), (r1, g1, f1, nz1) = res
+    assert g0 == g1 and g0[0] == g0[1]          # identical buffers on both ranks
+    assert nz0 and nz1
+    assert f0 == [0.0, 6.0, 12.0] and f1 == [18.0, 24.0]   # 5 frames -> 3 + 2, contiguous
