@@ -62,15 +62,29 @@ def kernel_class(name: str) -> str:
     return "pw_gemm_f32_kernel"
 
 
+def host_cores() -> int:
+    """Threads for the CPU leg: affinity mask, capped by the cgroup CPU quota and by the GPU
+    box's per-GPU CPU share (16); override with CASYNC_CPU_THREADS."""
+    if os.environ.get("CASYNC_CPU_THREADS"):
+        return max(1, int(os.environ["CASYNC_CPU_THREADS"]))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return min(n, 16)
+
+
 def cpu_baseline(sd_np, seconds: float):
     """The CPU oracle (a port of the reference's forward, torch-CPU fp32) on the host cores."""
     from calipsync_amd import recipe
     from oracle import unet_oracle
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     sd = unet_oracle.to_torch(sd_np)
     b = 8
