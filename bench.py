@@ -49,6 +49,8 @@ def parse():
 
 def kernel_class(name: str) -> str:
     """Group the plan's launches by the HIP kernel that runs them."""
+    if name.endswith(".fused"):
+        return "ir_fused_kernel"
     if name.endswith(".dw"):
         return "dw3x3_kernel"
     if name.endswith(".attn"):
@@ -180,7 +182,8 @@ def main():
         dom_name, dom = max(per.items(), key=lambda kv: kv[1]["ms"])
         tf = dom["flops"] / dom["ms"] / 1e9
         gbs = dom["bytes"] / dom["ms"] / 1e6
-        mfma_bound = dom_name == "pw_gemm_f32_kernel" and tf / MFMA_F32_PEAK_TF >= gbs / HBM_PEAK_GBS
+        mfma_bound = dom_name in ("pw_gemm_f32_kernel", "ir_fused_kernel") and \
+            tf / MFMA_F32_PEAK_TF >= gbs / HBM_PEAK_GBS
         roofline = {
             "kernel": dom_name,
             "bound": "mfma" if mfma_bound else "hbm",

@@ -56,6 +56,11 @@ int launch_pw_gemm(const float* a, int lda, const float* w, float* c, int ldc, i
 // ---- other operators -------------------------------------------------------
 int launch_dw3x3(const float* in, const float* w, const float* bias, float* out, int batch, int h,
                  int wdt, int c, int stride, hipStream_t stream);
+bool ir_fused_supported(int cin, int cout, int stride);
+int launch_ir_fused(const float* in, int ld_in, const float* w1, const float* b1, const float* wd,
+                    const float* bd, const float* w2, const float* b2, float* out, int ld_out,
+                    int batch, int h, int w, int cin, int cout, int stride, int res,
+                    hipStream_t stream);
 int launch_im2col3x3(const float* in, float* out, int batch, int h, int wdt, int c, int stride,
                      int pad, hipStream_t stream);
 int launch_upsample2x(const float* in, float* out, int ldc, int batch, int h, int wdt, int c,

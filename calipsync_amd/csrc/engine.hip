@@ -3,6 +3,7 @@
 // module/unet.py:314-345).  Mirrors calipsync_amd/arch.py (tests/test_abi.py checks the two
 // agree).  Everything is NHWC fp32 inside; NCHW only at the boundary.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -223,11 +224,18 @@ struct Runner {
   }
 };
 
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
 struct Plan {
   const casync_engine& e;
   Arena ar;
   Runner& r;
   int B;
+  bool fuse_ir = env_int("CASYNC_FUSE_IR", 1) != 0;      // A/B switch for the fused IR kernel
+  int fuse_min_hw = env_int("CASYNC_FUSE_MIN_HW", 32);   // fuse stages at least this large
 
   // GEMM wrapper with work accounting (algorithmic bytes: A + C once, W once)
   void gemm(const std::string& tag, const float* a, int lda, const std::string& wname, float* c,
@@ -247,6 +255,16 @@ struct Plan {
           const GemmEpilogue* extra = nullptr) {
     const std::string p = b.prefix;
     const long long m_in = (long long)B * b.hw_in * b.hw_in, m_out = (long long)B * b.hw_out() * b.hw_out();
+    if (fuse_ir && !extra && b.hw_in >= fuse_min_hw && ir_fused_supported(b.cin, b.cout, b.stride)) {
+      const double flops = 2.0 * (m_in * (double)b.cin * b.cexp() + 9.0 * m_out * b.cexp() +
+                                  (double)m_out * b.cexp() * b.cout);
+      r.run((p + ".fused").c_str(), flops, 4.0 * (m_in * (double)b.cin + (double)m_out * b.cout), [&] {
+        return launch_ir_fused(in, ld_in, e.W(p + ".pw1.w"), e.W(p + ".pw1.b"), e.W(p + ".dw.w"),
+                               e.W(p + ".dw.b"), e.W(p + ".pw2.w"), e.W(p + ".pw2.b"), out, ld_out, B,
+                               b.hw_in, b.hw_in, b.cin, b.cout, b.stride, b.res, r.s);
+      });
+      return;
+    }
     GemmEpilogue ep1;
     ep1.act = 1;
     gemm(p + ".pw1", in, ld_in, p + ".pw1.w", e1, b.cexp(), m_in, b.cexp(), b.cin, ep1);
@@ -547,6 +565,13 @@ int casync_op_pw_gemm(const float* a, int lda, const float* w, const float* bias
 int casync_op_dw3x3(const float* in, const float* w, const float* bias, float* out, int batch, int h,
                     int wdt, int c, int stride, casync_stream stream) {
   return launch_dw3x3(in, w, bias, out, batch, h, wdt, c, stride, (hipStream_t)stream);
+}
+int casync_op_ir_fused(const float* in, int ld_in, const float* w1, const float* b1, const float* wd,
+                       const float* bd, const float* w2, const float* b2, float* out, int ld_out,
+                       int batch, int h, int w, int cin, int cout, int stride, int res,
+                       casync_stream stream) {
+  return launch_ir_fused(in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out, batch, h, w, cin, cout, stride,
+                         res, (hipStream_t)stream);
 }
 int casync_op_im2col3x3(const float* in, float* out, int batch, int h, int wdt, int c, int stride,
                         int pad, casync_stream stream) {

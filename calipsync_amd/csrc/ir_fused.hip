@@ -1,0 +1,401 @@
+// Fused inverted-residual block for the high-resolution stages (160x160 / 80x80 / 32x32):
+//
+//   out = [x +] lrelu(W2 * lrelu(dw3x3(lrelu(W1 * x + b1)) + bd) + b2)
+//
+// replaces the PW -> BN -> LReLU -> DW3x3 -> BN -> LReLU -> PW -> BN -> LReLU chain of
+// InvertedResidual (reference module/unet.py:16-40) in ONE kernel: the 2x-expanded tensor
+// (the 13 MB/frame giant of up4) never touches HBM.  HBM traffic per
+// workgroup = input tile (+halo) + output tile; everything else lives in LDS.
+//
+// Workgroup = TH x 16 output pixels of one frame (TH = 8 stride 1, 4 stride 2), 4 waves.
+//   once:       stage the input tile with its 1-pixel halo  A[HP][CIN] -> LDS (zeros outside the image)
+//   per CC-channel chunk of the expanded tensor:
+//     P1  E[hp][CC]  = mask * lrelu(A[hp][:] . W1c^T + b1)    v_mfma_f32_16x16x4_f32
+//     P2  D[p][CC]   = lrelu(dw3x3(E) + bd)                    VALU, LDS b128 reads
+//     P3  acc[p][:] += D[p][:] . W2c^T                         v_mfma_f32_16x16x4_f32
+//   end:        + b2, LReLU, (+ x from the LDS tile), coalesced NHWC store.
+// The depthwise conv zero-pads the EXPANDED tensor, so halo positions outside the image are
+// forced to 0 after the expand (border tiles only), not lrelu(b1).
+//
+// Pipeline: the next chunk's weights are fetched into registers while the current chunk
+// computes and parked in the other half of a double-buffered LDS weight area, so a chunk costs
+// two barriers (after P1, after P2) and no exposed global-load latency.  LDS tiles carry no
+// padding; 16-B columns are XOR-swizzled by row (xs()) so the b128 fragment reads of 16
+// different rows land on different banks -- that keeps a workgroup under 80 KB and lets two
+// of them share a CU, which is what overlaps one group's VALU/LDS phases with the other's
+// MFMA phases.
+//
+// MFMA 16x16x4 f32 operand maps: lane l supplies A[i = l&15][k = l>>4], B[k = l>>4][j = l&15];
+// C/D: col = l&15, row = 4*(l>>4) + reg.  Fragments are read with one ds_read_b128 per four
+// k-steps (lane group q = l>>4 takes k = 16g+4q .. +3; A and B use the same k permutation).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int TW = 16;   // output tile width
+
+// Swizzled float offset of (row, col) in an unpadded [rows][RF] tile (RF floats per row).
+// The 16-B column index is XORed with a per-row key chosen so that 16 consecutive rows of
+// the same column fall into 16 different 16-B bank slots (256-B LDS bank row).
+template <int RF>
+__device__ __forceinline__ int xs(int row, int col) {
+  constexpr int R = RF / 4;                        // 16-B columns per row
+  constexpr int RPB = R >= 16 ? 1 : 16 / R;        // rows per 256-B bank row
+  constexpr int MASK = (R >= 16 ? 16 : R) - 1;
+  const int key = (row / RPB) & MASK;
+  return row * RF + ((((col >> 2) ^ key)) << 2) + (col & 3);
+}
+
+template <int CIN, int COUT, int STRIDE, int CC>
+struct IRGeom {
+  static constexpr int TH = STRIDE == 1 ? 8 : 4;
+  static constexpr int OP = TH * TW;                        // output pixels per tile
+  static constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
+  static constexpr int HP = IH * IW;                        // halo pixels
+  static constexpr int HPP = (HP + 63) / 64 * 64;           // padded to 4 waves x 16-row tiles
+  static constexpr int MT1 = HPP / 64;                      // P1 M-tiles per wave
+  static constexpr int NT1 = CC / 16;
+  static constexpr int MT3 = OP / 64;                       // P3 M-tiles per wave
+  static constexpr int NT3 = COUT / 16;
+  static constexpr int LDO = 36;                            // epilogue staging: 32 columns + 4
+  // one weight buffer: W1c [CC][CIN], W2c [COUT][CC], Wd [9][CC], b1 [CC], bd [CC]
+  static constexpr int wW1 = 0, wW2 = wW1 + CC * CIN, wWd = wW2 + COUT * CC, wB = wWd + 9 * CC;
+  static constexpr int WBUF = wB + 2 * CC;
+  // LDS carve (floats)
+  static constexpr int oA = 0;
+  static constexpr int oE = oA + HP * CIN;
+  static constexpr int oD = oE + HP * CC;
+  static constexpr int oW = oD + OP * CC;
+  static constexpr int total = oW + 2 * WBUF;
+  static_assert(OP * LDO <= total - oE, "epilogue staging must fit behind the input tile");
+  static_assert((HP * CIN) % 4 == 0 && (HP * CC) % 4 == 0 && WBUF % 4 == 0, "16-B aligned carve");
+  static_assert(total * 4 <= 160 * 1024, "LDS budget");
+  // per-thread register slots of one weight chunk in flight
+  static constexpr int NW1 = (CC * CIN / 4 + 255) / 256;
+  static constexpr int NW2 = (COUT * CC / 4 + 255) / 256;
+  static constexpr int NWD = (11 * CC / 4 + 255) / 256;    // Wd, b1, bd are contiguous per chunk in LDS
+};
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float lrelu_max(float v) { return fmaxf(v, v * CASYNC_LRELU_SLOPE); }
+
+template <int CIN, int CE, int COUT, int STRIDE, int CC>
+__global__ __launch_bounds__(256) void ir_fused_kernel(
+    const float* __restrict__ in, int ld_in, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ wd, const float* __restrict__ bd,
+    const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ out, int ld_out,
+    int H, int W, int Ho, int Wo, int res) {
+  using G = IRGeom<CIN, COUT, STRIDE, CC>;
+  constexpr int NCH = CE / CC;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem + G::oA;
+  float* sE = smem + G::oE;
+  float* sD = smem + G::oD;
+  float* sW = smem + G::oW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int b = blockIdx.z, oy0 = blockIdx.y * G::TH, ox0 = blockIdx.x * TW;
+  const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
+  const float* inb = in + (size_t)b * H * W * ld_in;
+  // does the halo leave the image?  (workgroup-uniform)
+  const bool border = iy0 < 0 || ix0 < 0 || iy0 + G::IH > H || ix0 + G::IW > W;
+
+  // ---- weight chunk: global -> registers (wload) and registers -> LDS (wstore) ----
+  f32x4 rw1[G::NW1], rw2[G::NW2], rwd[G::NWD];
+  auto wload = [&](int ce0) {
+#pragma unroll
+    for (int j = 0; j < G::NW1; ++j) {
+      const int idx = tid + 256 * j;
+      if (G::NW1 * 256 == CC * CIN / 4 || idx < CC * CIN / 4)
+        rw1[j] = *reinterpret_cast<const f32x4*>(w1 + (size_t)ce0 * CIN + idx * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < G::NW2; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < COUT * CC / 4) {
+        const int r = idx / (CC / 4), c4 = (idx - r * (CC / 4)) * 4;
+        rw2[j] = *reinterpret_cast<const f32x4*>(w2 + (size_t)r * CE + ce0 + c4);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < G::NWD; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < 11 * CC / 4) {
+        const int t = idx / (CC / 4), c4 = (idx - t * (CC / 4)) * 4;   // t: 0..8 taps, 9 = b1, 10 = bd
+        const float* src = t < 9 ? wd + (size_t)t * CE : (t == 9 ? b1 : bd);
+        rwd[j] = *reinterpret_cast<const f32x4*>(src + ce0 + c4);
+      }
+    }
+  };
+  auto wstore = [&](int buf) {
+    float* wb = sW + buf * G::WBUF;
+#pragma unroll
+    for (int j = 0; j < G::NW1; ++j) {
+      const int idx = tid + 256 * j;
+      if (G::NW1 * 256 == CC * CIN / 4 || idx < CC * CIN / 4) {
+        const int r = idx / (CIN / 4), c4 = (idx - r * (CIN / 4)) * 4;
+        *reinterpret_cast<f32x4*>(wb + G::wW1 + xs<CIN>(r, c4)) = rw1[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < G::NW2; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < COUT * CC / 4) {
+        const int r = idx / (CC / 4), c4 = (idx - r * (CC / 4)) * 4;
+        *reinterpret_cast<f32x4*>(wb + G::wW2 + xs<CC>(r, c4)) = rw2[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < G::NWD; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < 11 * CC / 4) *reinterpret_cast<f32x4*>(wb + G::wWd + idx * 4) = rwd[j];
+    }
+  };
+
+  wload(0);
+  // ---- stage the input tile (+halo), zeros outside the image ----
+  constexpr int NA = (G::HP * (CIN / 4) + 255) / 256;
+#pragma unroll 4
+  for (int j = 0; j < NA; ++j) {
+    const int idx = tid + 256 * j;
+    if (idx < G::HP * (CIN / 4)) {
+      const int hp = idx / (CIN / 4), c4 = (idx - hp * (CIN / 4)) * 4;
+      const int hy = hp / G::IW, hx = hp - hy * G::IW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+        v = *reinterpret_cast<const f32x4*>(inb + ((size_t)iy * W + ix) * ld_in + c4);
+      *reinterpret_cast<f32x4*>(sA + xs<CIN>(hp, c4)) = v;
+    }
+  }
+  wstore(0);
+  if (NCH > 1) wload(CC);
+  __syncthreads();
+
+  f32x4 acc3[G::MT3][G::NT3];
+#pragma unroll
+  for (int i = 0; i < G::MT3; ++i)
+#pragma unroll
+    for (int n = 0; n < G::NT3; ++n) acc3[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment rows of this lane (P1: halo rows, clamped into the tile; P3: output pixels)
+  int arow[G::MT1];
+#pragma unroll
+  for (int i = 0; i < G::MT1; ++i) {
+    const int row = 16 * (wave * G::MT1 + i) + l15;
+    arow[i] = row < G::HP ? row : G::HP - 1;   // MFMA pad rows re-read the last halo row; never stored
+  }
+
+#pragma unroll 1
+  for (int ch = 0; ch < NCH; ++ch) {
+    const float* wb = sW + (ch & 1) * G::WBUF;
+    // ---- P1: expand GEMM over the halo, [HPP x CIN] x [CIN x CC], bias preloaded into acc ----
+    {
+      f32x4 acc[G::MT1][G::NT1];
+#pragma unroll
+      for (int n = 0; n < G::NT1; ++n) {
+        const float bias = wb[G::wB + 16 * n + l15];
+#pragma unroll
+        for (int i = 0; i < G::MT1; ++i) acc[i][n] = f32x4{bias, bias, bias, bias};
+      }
+#pragma unroll
+      for (int g = 0; g < CIN / 16; ++g) {
+        f32x4 fa[G::MT1], fb[G::NT1];
+#pragma unroll
+        for (int i = 0; i < G::MT1; ++i)
+          fa[i] = *reinterpret_cast<const f32x4*>(sA + xs<CIN>(arow[i], 16 * g + 4 * q));
+#pragma unroll
+        for (int n = 0; n < G::NT1; ++n)
+          fb[n] = *reinterpret_cast<const f32x4*>(wb + G::wW1 + xs<CIN>(16 * n + l15, 16 * g + 4 * q));
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < G::MT1; ++i)
+#pragma unroll
+            for (int n = 0; n < G::NT1; ++n) acc[i][n] = mfma16(fa[i][s], fb[n][s], acc[i][n]);
+      }
+#pragma unroll
+      for (int i = 0; i < G::MT1; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int hp = 16 * (wave * G::MT1 + i) + 4 * q + r;
+          if (hp < G::HP) {
+            float m = 1.f;
+            if (border) {
+              const int hy = hp / G::IW, hx = hp - hy * G::IW;
+              const int iy = iy0 + hy, ix = ix0 + hx;
+              m = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? 1.f : 0.f;
+            }
+#pragma unroll
+            for (int n = 0; n < G::NT1; ++n) sE[xs<CC>(hp, 16 * n + l15)] = m * lrelu_max(acc[i][n][r]);
+          }
+        }
+    }
+    __syncthreads();  // E complete; every wave is done with the previous chunk's P3
+    if (ch + 1 < NCH) {
+      wstore((ch + 1) & 1);                       // park the next chunk's weights
+      if (ch + 2 < NCH) wload((ch + 2) * CC);     // and start fetching the one after
+    }
+
+    // ---- P2: depthwise 3x3 over E -> D (thread = 4 channels x several pixels) ----
+    {
+      constexpr int TPP = CC / 4, PPI = 256 / TPP;   // threads per pixel, pixels per iteration
+      const int c4 = (tid % TPP) * 4, p0 = tid / TPP;
+      f32x4 wt[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(wb + G::wWd + t * CC + c4);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(wb + G::wB + CC + c4);
+#pragma unroll
+      for (int j = 0; j < G::OP / PPI; ++j) {
+        const int p = p0 + PPI * j, py = p / TW, px = p - py * TW;
+        const int h0 = (py * STRIDE) * G::IW + px * STRIDE;
+        f32x4 a = bv;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+            a += *reinterpret_cast<const f32x4*>(sE + xs<CC>(h0 + ky * G::IW + kx, c4)) * wt[ky * 3 + kx];
+        a.x = lrelu_max(a.x); a.y = lrelu_max(a.y); a.z = lrelu_max(a.z); a.w = lrelu_max(a.w);
+        *reinterpret_cast<f32x4*>(sD + xs<CC>(p, c4)) = a;
+      }
+    }
+    __syncthreads();  // D complete (and the parked weights are visible)
+
+    // ---- P3: project GEMM, acc3[OP x COUT] += D[OP x CC] x W2c^T ----
+    {
+#pragma unroll
+      for (int g = 0; g < CC / 16; ++g) {
+        f32x4 fa[G::MT3], fb[G::NT3];
+#pragma unroll
+        for (int i = 0; i < G::MT3; ++i)
+          fa[i] = *reinterpret_cast<const f32x4*>(sD + xs<CC>(16 * (wave * G::MT3 + i) + l15, 16 * g + 4 * q));
+#pragma unroll
+        for (int n = 0; n < G::NT3; ++n)
+          fb[n] = *reinterpret_cast<const f32x4*>(wb + G::wW2 + xs<CC>(16 * n + l15, 16 * g + 4 * q));
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < G::MT3; ++i)
+#pragma unroll
+            for (int n = 0; n < G::NT3; ++n) acc3[i][n] = mfma16(fa[i][s], fb[n][s], acc3[i][n]);
+      }
+    }
+    // no barrier here: the next P1 writes E only, which nobody reads until after its barrier
+  }
+  __syncthreads();
+
+  // ---- epilogue: + b2, LReLU -> LDS staging (over E/D/W, 32 columns at a time) -> coalesced
+  //      NHWC rows (+ residual from the centre of the staged input tile) ----
+  float* sO = sE;
+  float* outb = out + (size_t)b * Ho * Wo * ld_out;
+#pragma unroll
+  for (int n0 = 0; n0 < G::NT3; n0 += 2) {
+    if (n0) __syncthreads();  // previous slice fully stored before it is overwritten
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+      const float bias = b2[16 * (n0 + nn) + l15];
+#pragma unroll
+      for (int i = 0; i < G::MT3; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = 16 * (wave * G::MT3 + i) + 4 * q + r;
+          sO[p * G::LDO + 16 * nn + l15] = lrelu_max(acc3[i][n0 + nn][r] + bias);
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G::OP * 8; idx += 256) {
+      const int p = idx >> 3, c4 = (idx & 7) * 4;
+      const int py = p / TW, px = p - py * TW;
+      const int oy = oy0 + py, ox = ox0 + px;
+      if (oy < Ho && ox < Wo) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(sO + p * G::LDO + c4);
+        const int c = 16 * n0 + c4;
+        if (res)  // stride 1, CIN == COUT: the block input is the centre of the staged tile
+          v += *reinterpret_cast<const f32x4*>(sA + xs<CIN>((py + 1) * G::IW + px + 1, c));
+        *reinterpret_cast<f32x4*>(outb + ((size_t)oy * Wo + ox) * ld_out + c) = v;
+      }
+    }
+  }
+}
+
+template <int CIN, int CE, int COUT, int STRIDE, int CC>
+int launch_inst(const float* in, int ld_in, const float* w1, const float* b1, const float* wd,
+                const float* bd, const float* w2, const float* b2, float* out, int ld_out, int batch,
+                int h, int w, int res, hipStream_t stream) {
+  using G = IRGeom<CIN, COUT, STRIDE, CC>;
+  constexpr size_t lds = (size_t)G::total * sizeof(float);
+  auto kern = ir_fused_kernel<CIN, CE, COUT, STRIDE, CC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    CASYNC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int ho = (h + 2 - 3) / STRIDE + 1, wo = (w + 2 - 3) / STRIDE + 1;
+  dim3 grid((wo + TW - 1) / TW, (ho + G::TH - 1) / G::TH, batch);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, in, ld_in, w1, b1, wd, bd, w2, b2, out,
+                     ld_out, h, w, ho, wo, res);
+  CASYNC_CHECK_HIP(hipGetLastError());
+  return CASYNC_OK;
+}
+
+}  // namespace
+
+bool ir_fused_supported(int cin, int cout, int stride) {
+  const int key = cin * 10000 + cout * 10 + stride;
+  switch (key) {
+    case 32 * 10000 + 32 * 10 + 1:
+    case 64 * 10000 + 32 * 10 + 1:
+    case 128 * 10000 + 32 * 10 + 1:
+    case 64 * 10000 + 64 * 10 + 1:
+    case 32 * 10000 + 64 * 10 + 2:
+    case 32 * 10000 + 64 * 10 + 1:
+    case 64 * 10000 + 128 * 10 + 1:
+    case 64 * 10000 + 128 * 10 + 2:
+      return true;
+  }
+  return false;
+}
+
+int launch_ir_fused(const float* in, int ld_in, const float* w1, const float* b1, const float* wd,
+                    const float* bd, const float* w2, const float* b2, float* out, int ld_out,
+                    int batch, int h, int w, int cin, int cout, int stride, int res,
+                    hipStream_t stream) {
+  CASYNC_REQUIRE(in && w1 && b1 && wd && bd && w2 && b2 && out, "ir_fused: null pointer");
+  CASYNC_REQUIRE(batch > 0 && batch <= 65535 && h > 1 && w > 1, "ir_fused: bad shape");
+  CASYNC_REQUIRE(ld_in >= cin && ld_in % 4 == 0 && ld_out >= cout && ld_out % 4 == 0, "ir_fused: bad ld");
+  CASYNC_REQUIRE(!res || (stride == 1 && cin == cout), "ir_fused: residual needs stride 1 and cin == cout");
+  CASYNC_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0, "ir_fused: alignment");
+  // CASYNC_IR_CC=16|32 overrides the per-shape chunk width (A/B experiments)
+  static const int cc_env = [] { const char* v = getenv("CASYNC_IR_CC"); return v ? atoi(v) : 0; }();
+#define IR_CASE(CI, CO, S, CCDEF)                                                                     \
+  if (cin == CI && cout == CO && stride == S) {                                                       \
+    const int cc = cc_env ? cc_env : CCDEF;                                                           \
+    if (cc == 16)                                                                                     \
+      return launch_inst<CI, 2 * CI, CO, S, 16>(in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out, batch, \
+                                                h, w, res, stream);                                   \
+    return launch_inst<CI, 2 * CI, CO, S, 32>(in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out, batch,  \
+                                              h, w, res, stream);                                     \
+  }
+#define IR_CASE16(CI, CO, S)                                                                        \
+  if (cin == CI && cout == CO && stride == S)                                                       \
+    return launch_inst<CI, 2 * CI, CO, S, 16>(in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out, batch, \
+                                              h, w, res, stream);
+  IR_CASE(32, 32, 1, 32)    // up4.ir1, up3.ir1
+  IR_CASE(64, 32, 1, 16)    // up4.ir0
+  IR_CASE16(128, 32, 1)     // up3.ir0 (CC=32 exceeds the LDS)
+  IR_CASE(64, 64, 1, 16)    // down1.ir1, up2.ir1
+  IR_CASE(32, 64, 2, 16)    // down1.ir0
+  IR_CASE(32, 64, 1, 16)    // audio conv1
+  IR_CASE(64, 128, 1, 16)   // audio conv2
+  IR_CASE16(64, 128, 2)     // down2.ir0
+#undef IR_CASE
+#undef IR_CASE16
+  casync_set_error("ir_fused: no instance for cin=%d cout=%d stride=%d", cin, cout, stride);
+  return CASYNC_ERR_ARG;
+}

@@ -114,6 +114,14 @@ int casync_op_pw_gemm(const float* a, int lda, const float* w, const float* bias
  * w is tap-major [9][C].                                                    */
 int casync_op_dw3x3(const float* in, const float* w, const float* bias, float* out,
                     int batch, int h, int wdt, int c, int stride, casync_stream stream);
+/* Whole inverted-residual block in one kernel (expanded tensor stays in LDS); the
+ * high-resolution stages use it.  Replaces InvertedResidual.forward
+ * (module/unet.py:16-40) with BN folded: w1 [2cin][cin], wd [9][2cin], w2 [cout][2cin].
+ * Returns CASYNC_ERR_ARG if (cin, cout, stride) has no instance.              */
+int casync_op_ir_fused(const float* in, int ld_in, const float* w1, const float* b1,
+                       const float* wd, const float* bd, const float* w2, const float* b2,
+                       float* out, int ld_out, int batch, int h, int w, int cin, int cout,
+                       int stride, int res, casync_stream stream);
 /* im2col for the two dense 3x3 stride-2 convs (module/unet.py:161-168):
  * out[B*Ho*Wo][9*C], column order (ky,kx,c).                                */
 int casync_op_im2col3x3(const float* in, float* out, int batch, int h, int wdt, int c,

@@ -182,3 +182,52 @@ def test_outc_head(lib):
     wd, bd = w.to(dev()), b.to(dev())
     ok(lib.casync_op_outc(ptr(nhwc(x)), 32, ptr(wd), ptr(bd), ptr(out), 2, stream()))
     assert (out.cpu() - ref).abs().max() < 2e-6
+
+
+IR_CASES = [  # (state_dict prefix, cin, cout, stride, res, h, w)
+    ("up4.conv.double_conv.0", 64, 32, 1, False, 160, 160),
+    ("up4.conv.double_conv.1", 32, 32, 1, True, 160, 160),
+    ("up3.conv.double_conv.0", 128, 32, 1, False, 80, 80),
+    ("up3.conv.double_conv.1", 32, 32, 1, True, 24, 40),        # ragged tiles
+    ("down1.maxpool_conv.0.double_conv.0", 32, 64, 2, False, 160, 160),
+    ("down1.maxpool_conv.0.double_conv.1", 64, 64, 1, True, 80, 80),
+    ("down2.maxpool_conv.0.double_conv.0", 64, 128, 2, False, 80, 80),   # 40-wide output: partial tile
+    ("down2.maxpool_conv.0.double_conv.0", 64, 128, 2, False, 37, 51),   # odd sizes
+    ("audio_model.conv1", 32, 64, 1, False, 32, 32),
+    ("audio_model.conv2", 64, 128, 1, False, 32, 32),
+]
+
+
+@pytest.mark.parametrize("prefix,cin,cout,stride,res,h,w", IR_CASES)
+def test_ir_fused_block(lib, recipe_sd, prefix, cin, cout, stride, res, h, w):
+    """Fused inverted residual vs the oracle's module on the recipe weights, reading from and
+    writing into channel slices of wider buffers (as the engine does for the concats)."""
+    from oracle import unet_oracle
+    sd = unet_oracle.to_torch(recipe_sd)
+    f = pack.fold(recipe_sd)
+    g = torch.Generator().manual_seed(h * 7 + cin)
+    b = 2
+    x = torch.randn(b, cin, h, w, generator=g)
+    ref = unet_oracle.inverted_residual(sd, prefix, x, stride, res)
+    ho, wo = ref.shape[2], ref.shape[3]
+    ld_in, ld_out = cin + 32, cout + 16
+    xin = torch.full((b, h, w, ld_in), 3.0)
+    xin[..., 32:] = x.permute(0, 2, 3, 1)
+    xin = xin.to(dev())
+    out = torch.full((b, ho, wo, ld_out), -5.0, device=dev())
+    T = lambda k: torch.from_numpy(f[f"{prefix}.{k}"].astype(np.float32)).contiguous().to(dev())
+    w1, b1, wd, bd, w2, b2 = T("pw1.w"), T("pw1.b"), T("dw.w"), T("dw.b"), T("pw2.w"), T("pw2.b")
+    ok(lib.casync_op_ir_fused(xin.data_ptr() + 32 * 4, ld_in, ptr(w1), ptr(b1), ptr(wd), ptr(bd), ptr(w2),
+                              ptr(b2), out.data_ptr() + 16 * 4, ld_out, b, h, w, cin, cout, stride,
+                              int(res), stream()))
+    o = out.cpu()
+    assert (o[..., :16] == -5).all()
+    got = o[..., 16:].permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < 3e-6, rel_err(got, ref)
+
+
+def test_ir_fused_rejects_unknown_shape(lib):
+    z = torch.zeros(1024, device=dev())
+    st = lib.casync_op_ir_fused(ptr(z), 48, ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), 48, 1, 4, 4,
+                                48, 48, 1, 0, stream())
+    assert st < 0 and b"no instance" in lib.casync_last_error()
