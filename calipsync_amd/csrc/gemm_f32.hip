@@ -17,12 +17,24 @@
 // `kh` takes k = 8g+4kh .. +3 of every group of 8 -- any k permutation is legal as long
 // as A and B use the same one.  Row stride 36 floats (144 B) makes those b128 reads
 // bank-conflict free (16 distinct 16-B slots per lane group).
+//
+// Epilogue: accumulators are transposed through LDS (the A/B staging area is dead by then)
+// so that bias / residual / activation run on float4 and every global access is a full
+// coalesced row segment, instead of 4-B-per-lane scatter in the MFMA C layout.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
+
+template <int BM, int BN>
+constexpr size_t gemm_lds_bytes() {
+  const size_t stage = 2ull * (BM + BN) * LDS_LD, ctile = (size_t)BM * (BN + 4);
+  return (stage > ctile ? stage : ctile) * sizeof(float);
+}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void pw_gemm_f32_kernel(const float* __restrict__ A, int lda,
@@ -33,9 +45,11 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_kernel(const float* __restric
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_PASS = BM / 32, B_PASS = BN / 32;
+  constexpr int LDC_S = BN + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                    // [2][BM][LDS_LD]
   float* Bs = smem + 2 * BM * LDS_LD;  // [2][BN][LDS_LD]
+  float* Cs = smem;                    // [BM][BN+4], epilogue only
 
   // XCD-aware tile order: blocks b, b+8, ... share an XCD (round-robin dispatch); give each
   // XCD a contiguous run of tiles so the N-tiles of one M-panel hit the same L2.  Bijective
@@ -120,34 +134,47 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_kernel(const float* __restric
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns one output column per N sub-tile, 16 rows per M sub-tile ----
+  // ---- epilogue 1: accumulators -> LDS tile (row-major) ----
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * (BN / WN) + j * 32 + r32;
-    const float bias = epi.bias ? epi.bias[n] : 0.f;
-    const float pscale = epi.pre_scale ? epi.pre_scale[n] : 1.f;
-    const float as = epi.aff_s ? epi.aff_s[n] : 1.f;
-    const float at = epi.aff_s ? epi.aff_t[n] : 0.f;
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mbase = m0 + wm * (BM / WM) + i * 32 + 4 * kh;
+    for (int j = 0; j < TN; ++j) {
+      float* cbase = Cs + (wm * (BM / WM) + i * 32 + 4 * kh) * LDC_S + wn * (BN / WN) + j * 32 + r32;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mbase + (r & 3) + 8 * (r >> 2);
-        if (m < M) {
-          float v = acc[i][j][r] + bias;
-          if (epi.pre_res) v += pscale * epi.pre_res[(size_t)m * epi.ld_pre + n];
-          if (epi.act) v = lrelu(v);
-          if (epi.post_res) v += epi.post_res[(size_t)m * epi.ld_post + n];
-          if (epi.aff_s && !epi.aff_on_acc) v = lrelu(v * as + at);
-          C[(size_t)m * ldc + n] = v;
-          if (epi.acc_out) {
-            float s = epi.acc_in[(size_t)m * epi.ld_acc + n] + v;
-            if (epi.aff_s && epi.aff_on_acc) s = lrelu(s * as + at);
-            epi.acc_out[(size_t)m * epi.ld_acc + n] = s;
-          }
-        }
+      for (int r = 0; r < 16; ++r) cbase[((r & 3) + 8 * (r >> 2)) * LDC_S] = acc[i][j][r];
+    }
+  __syncthreads();
+
+  // ---- epilogue 2: float4 rows: bias, residuals, activation, coalesced stores ----
+  constexpr int TPR = BN / 4;          // threads per output row
+  constexpr int RPP = 256 / TPR;       // rows per pass
+  const int c4 = (tid % TPR) * 4, rr = tid / TPR;
+  const int n = n0 + c4;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
+  const f32x4 bias = epi.bias ? *reinterpret_cast<const f32x4*>(epi.bias + n) : zero;
+  const f32x4 pscale = epi.pre_scale ? *reinterpret_cast<const f32x4*>(epi.pre_scale + n) : one;
+  const f32x4 as = epi.aff_s ? *reinterpret_cast<const f32x4*>(epi.aff_s + n) : one;
+  const f32x4 at = epi.aff_s ? *reinterpret_cast<const f32x4*>(epi.aff_t + n) : zero;
+#pragma unroll 4
+  for (int p = 0; p < BM / RPP; ++p) {
+    const int row = rr + RPP * p, m = m0 + row;
+    if (m >= M) break;
+    f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC_S + c4) + bias;
+    if (epi.pre_res) v += pscale * *reinterpret_cast<const f32x4*>(epi.pre_res + (size_t)m * epi.ld_pre + n);
+    if (epi.act) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
+    if (epi.post_res) v += *reinterpret_cast<const f32x4*>(epi.post_res + (size_t)m * epi.ld_post + n);
+    if (epi.aff_s && !epi.aff_on_acc) {
+      v = v * as + at;
+      v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w);
+    }
+    *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n) = v;
+    if (epi.acc_out) {
+      f32x4 s = *reinterpret_cast<const f32x4*>(epi.acc_in + (size_t)m * epi.ld_acc + n) + v;
+      if (epi.aff_s && epi.aff_on_acc) {
+        s = s * as + at;
+        s.x = lrelu(s.x); s.y = lrelu(s.y); s.z = lrelu(s.z); s.w = lrelu(s.w);
       }
+      *reinterpret_cast<f32x4*>(epi.acc_out + (size_t)m * epi.ld_acc + n) = s;
     }
   }
 }
@@ -155,7 +182,7 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_kernel(const float* __restric
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const float* a, int lda, const float* w, float* c, int ldc, int m, int n, int k,
                const GemmEpilogue& epi, hipStream_t stream) {
-  constexpr size_t lds = 2ull * (BM + BN) * LDS_LD * sizeof(float);
+  constexpr size_t lds = gemm_lds_bytes<BM, BN>();
   static bool attr_set = false;
   auto kern = pw_gemm_f32_kernel<BM, BN, WM, WN>;
   if (!attr_set) {
@@ -172,6 +199,29 @@ int launch_cfg(const float* a, int lda, const float* w, float* c, int ldc, int m
   return CASYNC_OK;
 }
 
+// Tile choice.  On a 256-CU chip a launch of G workgroups finishes after ceil(G/256) "rounds" of
+// one tile per CU (co-resident tiles share the CU's matrix pipes, so they add, not overlap);
+// pick the tile that minimises rounds x tile area, preferring the larger tile on ties.
+enum Cfg { C128x128 = 0, C128x64, C64x64, C128x32, CFG_COUNT };
+
+int pick_cfg(int m, int n) {
+  static const int forced = [] { const char* v = getenv("CASYNC_GEMM_CFG"); return v ? atoi(v) : -1; }();
+  struct T { Cfg id; int bm, bn; };
+  const T tiles[] = {{C128x128, 128, 128}, {C128x64, 128, 64}, {C64x64, 64, 64}, {C128x32, 128, 32}};
+  if (forced >= 0 && forced < CFG_COUNT && n % tiles[forced].bn == 0) return forced;
+  int best = -1;
+  double best_cost = 0;
+  for (const T& t : tiles) {
+    if (n % t.bn) continue;
+    const long long g = (long long)((m + t.bm - 1) / t.bm) * (n / t.bn);
+    const double rounds = (double)((g + 255) / 256);
+    // small per-round overhead so that, when rounds x area ties, fewer / larger tiles win
+    const double cost = rounds * (t.bm * t.bn + 600.0);
+    if (best < 0 || cost < best_cost) best = t.id, best_cost = cost;
+  }
+  return best;
+}
+
 }  // namespace
 
 int launch_pw_gemm(const float* a, int lda, const float* w, float* c, int ldc, int m, int n, int k,
@@ -181,10 +231,17 @@ int launch_pw_gemm(const float* a, int lda, const float* w, float* c, int ldc, i
   CASYNC_REQUIRE(k % BK == 0, "pw_gemm: K=%d must be a multiple of %d", k, BK);
   CASYNC_REQUIRE(n % 32 == 0, "pw_gemm: N=%d must be a multiple of 32", n);
   CASYNC_REQUIRE(lda % 4 == 0 && lda >= k, "pw_gemm: lda=%d (K=%d) must be >= K and a multiple of 4", lda, k);
-  CASYNC_REQUIRE(ldc >= n, "pw_gemm: ldc=%d < N=%d", ldc, n);
-  CASYNC_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)w % 16) == 0, "pw_gemm: A/W must be 16-B aligned");
+  CASYNC_REQUIRE(ldc >= n && ldc % 4 == 0, "pw_gemm: ldc=%d must be >= N=%d and a multiple of 4", ldc, n);
+  CASYNC_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)c % 16) == 0,
+                 "pw_gemm: A/W/C must be 16-B aligned");
   CASYNC_REQUIRE(!epi.acc_out || epi.acc_in, "pw_gemm: acc_out without acc_in");
-  if (n % 128 == 0) return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream);
-  if (n % 64 == 0) return launch_cfg<128, 64, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream);
-  return launch_cfg<128, 32, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream);
+  CASYNC_REQUIRE((!epi.pre_res || epi.ld_pre % 4 == 0) && (!epi.post_res || epi.ld_post % 4 == 0) &&
+                     (!epi.acc_out || epi.ld_acc % 4 == 0),
+                 "pw_gemm: residual leading dimensions must be multiples of 4");
+  switch (pick_cfg(m, n)) {
+    case C128x128: return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream);
+    case C128x64: return launch_cfg<128, 64, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream);
+    case C64x64: return launch_cfg<64, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream);
+    default: return launch_cfg<128, 32, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream);
+  }
 }
