@@ -178,6 +178,10 @@ struct casync_engine {
   int device = 0;
   const float* w = nullptr;  // packed weights on the device
   float* owned = nullptr;
+  // second stream for the audio encoder, which is independent of the face encoder until the
+  // fusion MLP (module/unet.py:315-321): forked/joined with events inside casync_forward
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   const float* W(const std::string& name) const { return w + layout().off(name); }
 };
 
@@ -234,6 +238,8 @@ struct Plan {
   Arena ar;
   Runner& r;
   int B;
+  hipStream_t aux = nullptr;          // engine's second stream (null = no overlap)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool fuse_ir = env_int("CASYNC_FUSE_IR", 1) != 0;      // A/B switch for the fused IR kernel
   int fuse_min_hw = env_int("CASYNC_FUSE_MIN_HW", 32);   // fuse stages at least this large
 
@@ -285,16 +291,18 @@ struct Plan {
   void forward(const float* x, const float* audio, float* out) {
     using A = Arena;
     float *E1 = ar[A::E1], *E2 = ar[A::E2], *T0 = ar[A::T0];
-    // ---------------- face encoder (module/unet.py:315-319)
-    r.run("inc", 2.0 * B * 25600 * (72 + 108 + 384), 4.0 * B * 25600 * (6 + 32), [&] {
-      return launch_inc(x, e.W("inc.inconv.0.fused"), ar[A::CAT4] + 32, 64, B, r.s);
-    });
-    struct Skip { float* p; int ld; };
-    const Skip sk[5] = {{ar[A::CAT4] + 32, 64},   {ar[A::CAT3] + 64, 128}, {ar[A::CAT2] + 128, 256},
-                        {ar[A::CAT1] + 256, 512}, {ar[A::CATA], 1024}};
-    for (int i = 0; i < 4; ++i) {
-      ir(kDown[i][0], sk[i].p, sk[i].ld, T0, kDown[i][0].cout, E1, E2);
-      ir(kDown[i][1], T0, kDown[i][1].cin, sk[i + 1].p, sk[i + 1].ld, E1, E2);
+    // The audio encoder and the face encoder are independent until the fusion MLP; with a
+    // second stream they run concurrently and the many small 10x10 / 16x16 audio launches fill
+    // CUs the face encoder leaves idle.  Profiling mode keeps everything on one stream.
+    const bool overlap = aux && !r.profile;
+    hipStream_t main_s = r.s;
+    if (overlap) {
+      if (hipEventRecord(ev_fork, main_s) != hipSuccess || hipStreamWaitEvent(aux, ev_fork, 0) != hipSuccess) {
+        casync_set_error("forward: fork onto the audio stream failed");
+        r.status = CASYNC_ERR_HIP;
+        return;
+      }
+      r.s = aux;
     }
     // ---------------- audio encoder (module/unet.py:177-194)
     float *AE1 = ar[A::AE1], *AE2 = ar[A::AE2];
@@ -325,6 +333,25 @@ struct Plan {
       bn7.aff_s = e.W("audio_model.bn7.s");
       bn7.aff_t = e.W("audio_model.bn7.t");
       ir(kAudio[4], ar[A::AC6], 512, ar[A::CATA] + 512, 1024, AE1, AE2, &bn7);
+    }
+    if (overlap) {
+      if (r.status == CASYNC_OK && hipEventRecord(ev_join, aux) != hipSuccess) r.status = CASYNC_ERR_HIP;
+      r.s = main_s;
+    }
+    // ---------------- face encoder (module/unet.py:315-319)
+    r.run("inc", 2.0 * B * 25600 * (72 + 108 + 384), 4.0 * B * 25600 * (6 + 32), [&] {
+      return launch_inc(x, e.W("inc.inconv.0.fused"), ar[A::CAT4] + 32, 64, B, r.s);
+    });
+    struct Skip { float* p; int ld; };
+    const Skip sk[5] = {{ar[A::CAT4] + 32, 64},   {ar[A::CAT3] + 64, 128}, {ar[A::CAT2] + 128, 256},
+                        {ar[A::CAT1] + 256, 512}, {ar[A::CATA], 1024}};
+    for (int i = 0; i < 4; ++i) {
+      ir(kDown[i][0], sk[i].p, sk[i].ld, T0, kDown[i][0].cout, E1, E2);
+      ir(kDown[i][1], T0, kDown[i][1].cin, sk[i + 1].p, sk[i + 1].ld, E1, E2);
+    }
+    if (overlap && r.status == CASYNC_OK && hipStreamWaitEvent(main_s, ev_join, 0) != hipSuccess) {
+      casync_set_error("forward: join of the audio stream failed");
+      r.status = CASYNC_ERR_HIP;
     }
     // ---------------- fusion (module/unet.py:323-326): tx = bn_tx(cat + mlp(cat))
     const long long M10 = (long long)B * 100;
@@ -454,6 +481,12 @@ int casync_create(int device_id, casync_handle* out) {
 
 void casync_destroy(casync_handle h) {
   if (!h) return;
+  if (h->aux) {
+    (void)hipStreamSynchronize(h->aux);
+    (void)hipStreamDestroy(h->aux);
+    (void)hipEventDestroy(h->ev_fork);
+    (void)hipEventDestroy(h->ev_join);
+  }
   if (h->owned) {
     (void)hipSetDevice(h->device);
     (void)hipFree(h->owned);
@@ -489,6 +522,16 @@ int casync_forward(casync_handle h, const float* x, const float* a, float* out, 
   r.s = (hipStream_t)stream;
   Plan p{*h, Arena(), r, batch};
   p.ar.bind(ws, batch);
+  if (env_int("CASYNC_OVERLAP", 1)) {
+    if (!h->aux) {  // lazily, on the caller's current device (== h->device)
+      CASYNC_CHECK_HIP(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+      CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+      CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    p.aux = h->aux;
+    p.ev_fork = h->ev_fork;
+    p.ev_join = h->ev_join;
+  }
   p.forward(x, a, out);
   return r.status;
 }
