@@ -8,7 +8,9 @@
 // workgroup = input tile (+halo) + output tile; everything else lives in LDS.
 //
 // Workgroup = TH x 16 output pixels of one frame (TH = 8 stride 1, 4 stride 2), 4 waves.
-//   once:       stage the input tile with its 1-pixel halo  A[HP][CIN] -> LDS (zeros outside the image)
+//   once:       each wave loads the MFMA A-fragments of ITS halo rows (input tile + 1-pixel halo,
+//               zeros outside the image) straight from HBM into registers; they are reused by
+//               every chunk, so the input tile never occupies LDS
 //   per CC-channel chunk of the expanded tensor:
 //     P1  E[hp][CC]  = mask * lrelu(A[hp][:] . W1c^T + b1)    v_mfma_f32_16x16x4_f32
 //     P2  D[p][CC]   = lrelu(dw3x3(E) + bd)                    VALU, LDS b128 reads
@@ -21,9 +23,9 @@
 // computes and parked in the other half of a double-buffered LDS weight area, so a chunk costs
 // two barriers (after P1, after P2) and no exposed global-load latency.  LDS tiles carry no
 // padding; 16-B columns are XOR-swizzled by row (xs()) so the b128 fragment reads of 16
-// different rows land on different banks -- that keeps a workgroup under 80 KB and lets two
-// of them share a CU, which is what overlaps one group's VALU/LDS phases with the other's
-// MFMA phases.
+// different rows land on different banks.  With A in registers a workgroup needs ~35 KB of
+// LDS, so 3-4 of them share a CU: that is what overlaps one group's VALU/LDS phases (P2,
+// staging, epilogue) with the others' MFMA phases.
 //
 // MFMA 16x16x4 f32 operand maps: lane l supplies A[i = l&15][k = l>>4], B[k = l>>4][j = l&15];
 // C/D: col = l&15, row = 4*(l>>4) + reg.  Fragments are read with one ds_read_b128 per four
@@ -64,13 +66,13 @@ struct IRGeom {
   static constexpr int wW1 = 0, wW2 = wW1 + CC * CIN, wWd = wW2 + COUT * CC, wB = wWd + 9 * CC;
   static constexpr int WBUF = wB + 2 * CC;
   // LDS carve (floats)
-  static constexpr int oA = 0;
-  static constexpr int oE = oA + HP * CIN;
+  static constexpr int oE = 0;
   static constexpr int oD = oE + HP * CC;
   static constexpr int oW = oD + OP * CC;
   static constexpr int total = oW + 2 * WBUF;
-  static_assert(OP * LDO <= total - oE, "epilogue staging must fit behind the input tile");
-  static_assert((HP * CIN) % 4 == 0 && (HP * CC) % 4 == 0 && WBUF % 4 == 0, "16-B aligned carve");
+  static_assert(OP * LDO <= total, "epilogue staging must fit in E+D+W");
+  static_assert((HP * CC) % 4 == 0 && (OP * CC) % 4 == 0 && WBUF % 4 == 0, "16-B aligned carve");
+  static constexpr int KG = CIN / 16;                       // k-groups of 16: one A-fragment float4 each
   static_assert(total * 4 <= 160 * 1024, "LDS budget");
   // per-thread register slots of one weight chunk in flight
   static constexpr int NW1 = (CC * CIN / 4 + 255) / 256;
@@ -83,8 +85,17 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 __device__ __forceinline__ float lrelu_max(float v) { return fmaxf(v, v * CASYNC_LRELU_SLOPE); }
 
+// Waves per SIMD the register allocator must leave room for (= co-resident workgroups per
+// CU): A fragments + both accumulator sets + ~70 registers of addressing / staging.
+template <int CIN, int COUT, int STRIDE, int CC>
+constexpr int ir_min_waves() {
+  using G = IRGeom<CIN, COUT, STRIDE, CC>;
+  constexpr int est = 4 * (G::MT1 * G::KG + G::MT3 * G::NT3 + G::MT1 * G::NT1) + 70;
+  return est <= 128 ? 4 : (est <= 168 ? 3 : 2);
+}
+
 template <int CIN, int CE, int COUT, int STRIDE, int CC>
-__global__ __launch_bounds__(256) void ir_fused_kernel(
+__global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void ir_fused_kernel(
     const float* __restrict__ in, int ld_in, const float* __restrict__ w1,
     const float* __restrict__ b1, const float* __restrict__ wd, const float* __restrict__ bd,
     const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ out, int ld_out,
@@ -92,7 +103,6 @@ __global__ __launch_bounds__(256) void ir_fused_kernel(
   using G = IRGeom<CIN, COUT, STRIDE, CC>;
   constexpr int NCH = CE / CC;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sA = smem + G::oA;
   float* sE = smem + G::oE;
   float* sD = smem + G::oD;
   float* sW = smem + G::oW;
@@ -158,20 +168,19 @@ __global__ __launch_bounds__(256) void ir_fused_kernel(
   };
 
   wload(0);
-  // ---- stage the input tile (+halo), zeros outside the image ----
-  constexpr int NA = (G::HP * (CIN / 4) + 255) / 256;
-#pragma unroll 4
-  for (int j = 0; j < NA; ++j) {
-    const int idx = tid + 256 * j;
-    if (idx < G::HP * (CIN / 4)) {
-      const int hp = idx / (CIN / 4), c4 = (idx - hp * (CIN / 4)) * 4;
-      const int hy = hp / G::IW, hx = hp - hy * G::IW;
-      const int iy = iy0 + hy, ix = ix0 + hx;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-        v = *reinterpret_cast<const f32x4*>(inb + ((size_t)iy * W + ix) * ld_in + c4);
-      *reinterpret_cast<f32x4*>(sA + xs<CIN>(hp, c4)) = v;
-    }
+  // ---- A fragments of this wave's halo rows: HBM -> registers, once (zeros outside the image;
+  //      MFMA pad rows >= HP are zero too and never stored) ----
+  f32x4 fa[G::MT1][G::KG];
+#pragma unroll
+  for (int i = 0; i < G::MT1; ++i) {
+    const int hp = 16 * (wave * G::MT1 + i) + l15;
+    const int hy = hp / G::IW, hx = hp - hy * G::IW;
+    const int iy = iy0 + hy, ix = ix0 + hx;
+    const bool ok = hp < G::HP && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const float* src = inb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * ld_in + 4 * q;
+#pragma unroll
+    for (int g = 0; g < G::KG; ++g)
+      fa[i][g] = ok ? *reinterpret_cast<const f32x4*>(src + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   wstore(0);
   if (NCH > 1) wload(CC);
@@ -182,14 +191,6 @@ __global__ __launch_bounds__(256) void ir_fused_kernel(
   for (int i = 0; i < G::MT3; ++i)
 #pragma unroll
     for (int n = 0; n < G::NT3; ++n) acc3[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // fragment rows of this lane (P1: halo rows, clamped into the tile; P3: output pixels)
-  int arow[G::MT1];
-#pragma unroll
-  for (int i = 0; i < G::MT1; ++i) {
-    const int row = 16 * (wave * G::MT1 + i) + l15;
-    arow[i] = row < G::HP ? row : G::HP - 1;   // MFMA pad rows re-read the last halo row; never stored
-  }
 
 #pragma unroll 1
   for (int ch = 0; ch < NCH; ++ch) {
@@ -204,11 +205,8 @@ __global__ __launch_bounds__(256) void ir_fused_kernel(
         for (int i = 0; i < G::MT1; ++i) acc[i][n] = f32x4{bias, bias, bias, bias};
       }
 #pragma unroll
-      for (int g = 0; g < CIN / 16; ++g) {
-        f32x4 fa[G::MT1], fb[G::NT1];
-#pragma unroll
-        for (int i = 0; i < G::MT1; ++i)
-          fa[i] = *reinterpret_cast<const f32x4*>(sA + xs<CIN>(arow[i], 16 * g + 4 * q));
+      for (int g = 0; g < G::KG; ++g) {
+        f32x4 fb[G::NT1];
 #pragma unroll
         for (int n = 0; n < G::NT1; ++n)
           fb[n] = *reinterpret_cast<const f32x4*>(wb + G::wW1 + xs<CIN>(16 * n + l15, 16 * g + 4 * q));
@@ -217,7 +215,7 @@ __global__ __launch_bounds__(256) void ir_fused_kernel(
 #pragma unroll
           for (int i = 0; i < G::MT1; ++i)
 #pragma unroll
-            for (int n = 0; n < G::NT1; ++n) acc[i][n] = mfma16(fa[i][s], fb[n][s], acc[i][n]);
+            for (int n = 0; n < G::NT1; ++n) acc[i][n] = mfma16(fa[i][g][s], fb[n][s], acc[i][n]);
       }
 #pragma unroll
       for (int i = 0; i < G::MT1; ++i)
@@ -232,7 +230,7 @@ __global__ __launch_bounds__(256) void ir_fused_kernel(
               m = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? 1.f : 0.f;
             }
 #pragma unroll
-            for (int n = 0; n < G::NT1; ++n) sE[xs<CC>(hp, 16 * n + l15)] = m * lrelu_max(acc[i][n][r]);
+            for (int n = 0; n < G::NT1; ++n) sE[hp * CC + 16 * n + l15] = m * lrelu_max(acc[i][n][r]);
           }
         }
     }
@@ -242,26 +240,33 @@ __global__ __launch_bounds__(256) void ir_fused_kernel(
       if (ch + 2 < NCH) wload((ch + 2) * CC);     // and start fetching the one after
     }
 
-    // ---- P2: depthwise 3x3 over E -> D (thread = 4 channels x several pixels) ----
+    // ---- P2: depthwise 3x3 over E -> D (thread = 4 channels x several pixels).  E is read
+    //      linearly (consecutive lanes = consecutive 16-B columns of consecutive pixels), so it
+    //      needs no swizzle; taps are the outer loop so only one weight vector is live ----
     {
-      constexpr int TPP = CC / 4, PPI = 256 / TPP;   // threads per pixel, pixels per iteration
+      constexpr int TPP = CC / 4, PPI = 256 / TPP, NPX = G::OP / PPI;
       const int c4 = (tid % TPP) * 4, p0 = tid / TPP;
-      f32x4 wt[9];
-#pragma unroll
-      for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(wb + G::wWd + t * CC + c4);
       const f32x4 bv = *reinterpret_cast<const f32x4*>(wb + G::wB + CC + c4);
+      f32x4 a[NPX];
+      const float* e0[NPX];
 #pragma unroll
-      for (int j = 0; j < G::OP / PPI; ++j) {
+      for (int j = 0; j < NPX; ++j) {
         const int p = p0 + PPI * j, py = p / TW, px = p - py * TW;
-        const int h0 = (py * STRIDE) * G::IW + px * STRIDE;
-        f32x4 a = bv;
+        e0[j] = sE + ((py * STRIDE) * G::IW + px * STRIDE) * CC + c4;
+        a[j] = bv;
+      }
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+      for (int t = 0; t < 9; ++t) {
+        const f32x4 wt = *reinterpret_cast<const f32x4*>(wb + G::wWd + t * CC + c4);
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx)
-            a += *reinterpret_cast<const f32x4*>(sE + xs<CC>(h0 + ky * G::IW + kx, c4)) * wt[ky * 3 + kx];
-        a.x = lrelu_max(a.x); a.y = lrelu_max(a.y); a.z = lrelu_max(a.z); a.w = lrelu_max(a.w);
-        *reinterpret_cast<f32x4*>(sD + xs<CC>(p, c4)) = a;
+        for (int j = 0; j < NPX; ++j)
+          a[j] += *reinterpret_cast<const f32x4*>(e0[j] + ((t / 3) * G::IW + (t % 3)) * CC) * wt;
+      }
+#pragma unroll
+      for (int j = 0; j < NPX; ++j) {
+        f32x4 v = a[j];
+        v.x = lrelu_max(v.x); v.y = lrelu_max(v.y); v.z = lrelu_max(v.z); v.w = lrelu_max(v.w);
+        *reinterpret_cast<f32x4*>(sD + xs<CC>(p0 + PPI * j, c4)) = v;
       }
     }
     __syncthreads();  // D complete (and the parked weights are visible)
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(256) void ir_fused_kernel(
   __syncthreads();
 
   // ---- epilogue: + b2, LReLU -> LDS staging (over E/D/W, 32 columns at a time) -> coalesced
-  //      NHWC rows (+ residual from the centre of the staged input tile) ----
+  //      NHWC rows (+ residual) ----
   float* sO = sE;
   float* outb = out + (size_t)b * Ho * Wo * ld_out;
 #pragma unroll
@@ -315,8 +320,8 @@ __global__ __launch_bounds__(256) void ir_fused_kernel(
       if (oy < Ho && ox < Wo) {
         f32x4 v = *reinterpret_cast<const f32x4*>(sO + p * G::LDO + c4);
         const int c = 16 * n0 + c4;
-        if (res)  // stride 1, CIN == COUT: the block input is the centre of the staged tile
-          v += *reinterpret_cast<const f32x4*>(sA + xs<CIN>((py + 1) * G::IW + px + 1, c));
+        if (res)  // stride 1, CIN == COUT: the block input pixel (an L2 hit: this tile just read it)
+          v += *reinterpret_cast<const f32x4*>(inb + ((size_t)oy * W + ox) * ld_in + c);
         *reinterpret_cast<f32x4*>(outb + ((size_t)oy * Wo + ox) * ld_out + c) = v;
       }
     }
@@ -371,31 +376,19 @@ int launch_ir_fused(const float* in, int ld_in, const float* w1, const float* b1
   CASYNC_REQUIRE(ld_in >= cin && ld_in % 4 == 0 && ld_out >= cout && ld_out % 4 == 0, "ir_fused: bad ld");
   CASYNC_REQUIRE(!res || (stride == 1 && cin == cout), "ir_fused: residual needs stride 1 and cin == cout");
   CASYNC_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0, "ir_fused: alignment");
-  // CASYNC_IR_CC=16|32 overrides the per-shape chunk width (A/B experiments)
-  static const int cc_env = [] { const char* v = getenv("CASYNC_IR_CC"); return v ? atoi(v) : 0; }();
-#define IR_CASE(CI, CO, S, CCDEF)                                                                     \
-  if (cin == CI && cout == CO && stride == S) {                                                       \
-    const int cc = cc_env ? cc_env : CCDEF;                                                           \
-    if (cc == 16)                                                                                     \
-      return launch_inst<CI, 2 * CI, CO, S, 16>(in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out, batch, \
-                                                h, w, res, stream);                                   \
-    return launch_inst<CI, 2 * CI, CO, S, 32>(in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out, batch,  \
-                                              h, w, res, stream);                                     \
-  }
-#define IR_CASE16(CI, CO, S)                                                                        \
+#define IR_CASE(CI, CO, S)                                                                          \
   if (cin == CI && cout == CO && stride == S)                                                       \
     return launch_inst<CI, 2 * CI, CO, S, 16>(in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out, batch, \
                                               h, w, res, stream);
-  IR_CASE(32, 32, 1, 32)    // up4.ir1, up3.ir1
-  IR_CASE(64, 32, 1, 16)    // up4.ir0
-  IR_CASE16(128, 32, 1)     // up3.ir0 (CC=32 exceeds the LDS)
-  IR_CASE(64, 64, 1, 16)    // down1.ir1, up2.ir1
-  IR_CASE(32, 64, 2, 16)    // down1.ir0
-  IR_CASE(32, 64, 1, 16)    // audio conv1
-  IR_CASE(64, 128, 1, 16)   // audio conv2
-  IR_CASE16(64, 128, 2)     // down2.ir0
+  IR_CASE(32, 32, 1)    // up4.ir1, up3.ir1
+  IR_CASE(64, 32, 1)    // up4.ir0
+  IR_CASE(128, 32, 1)   // up3.ir0
+  IR_CASE(64, 64, 1)    // down1.ir1, up2.ir1
+  IR_CASE(32, 64, 2)    // down1.ir0
+  IR_CASE(32, 64, 1)    // audio conv1
+  IR_CASE(64, 128, 1)   // audio conv2
+  IR_CASE(64, 128, 2)   // down2.ir0
 #undef IR_CASE
-#undef IR_CASE16
   casync_set_error("ir_fused: no instance for cin=%d cout=%d stride=%d", cin, cout, stride);
   return CASYNC_ERR_ARG;
 }
