@@ -47,23 +47,6 @@ def parse():
     return ap.parse_args()
 
 
-def kernel_class(name: str) -> str:
-    """Group the plan's launches by the HIP kernel that runs them."""
-    if name.endswith(".fused"):
-        return "ir_fused_kernel"
-    if name.endswith(".dw"):
-        return "dw3x3_kernel"
-    if name.endswith(".attn"):
-        return "cross_attention_kernel"
-    if name.endswith(".im2col"):
-        return "im2col3x3_kernel"
-    if name.endswith(".bilinear"):
-        return "upsample2x_kernel"
-    if name in ("inc", "outc", "audio.nchw_to_nhwc"):
-        return name + "_kernel"
-    return "pw_gemm_f32_kernel"
-
-
 def host_cores() -> int:
     """Threads for the CPU leg: affinity mask, capped by the cgroup CPU quota and by the GPU
     box's per-GPU CPU share (16); override with CASYNC_CPU_THREADS."""
@@ -168,21 +151,21 @@ def main():
         reps = 3
         for _ in range(reps):
             for row in net.profile(x, a):
-                c = per.setdefault(kernel_class(row["name"]), {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
+                c = per.setdefault(row["kernel"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
                 c["ms"] += row["ms"]; c["flops"] += row["flops"]; c["bytes"] += row["bytes"]; c["n"] += 1
         if args.kernel_table:
             tot = sum(c["ms"] for c in per.values())
             for k, c in sorted(per.items(), key=lambda kv: -kv[1]["ms"]):
-                print(f"{k:28s} {c['n'] // reps:4d} launches {c['ms'] / reps:9.3f} ms {100 * c['ms'] / tot:5.1f}%  "
+                print(f"{k:40s} {c['n'] // reps:4d} launches {c['ms'] / reps:9.3f} ms {100 * c['ms'] / tot:5.1f}%  "
                       f"{c['flops'] / c['ms'] / 1e9:8.1f} TFLOP/s {c['bytes'] / c['ms'] / 1e6:8.1f} GB/s", file=sys.stderr)
             rows = net.profile(x, a)
             for r in rows:
-                print(f"  {r['name']:48s} {r['ms']:8.3f} ms {r['flops'] / max(r['ms'], 1e-6) / 1e9:8.1f} TF "
+                print(f"  {r['name']:48s} {r['kernel']:38s} {r['ms']:8.3f} ms {r['flops'] / max(r['ms'], 1e-6) / 1e9:8.1f} TF "
                       f"{r['bytes'] / max(r['ms'], 1e-6) / 1e6:8.1f} GB/s", file=sys.stderr)
         dom_name, dom = max(per.items(), key=lambda kv: kv[1]["ms"])
         tf = dom["flops"] / dom["ms"] / 1e9
         gbs = dom["bytes"] / dom["ms"] / 1e6
-        mfma_bound = dom_name in ("pw_gemm_f32_kernel", "ir_fused_kernel") and \
+        mfma_bound = dom_name.startswith(("pw_gemm_f32_kernel", "ir_fused_kernel")) and \
             tf / MFMA_F32_PEAK_TF >= gbs / HBM_PEAK_GBS
         roofline = {
             "kernel": dom_name,

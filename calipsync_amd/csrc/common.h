@@ -50,6 +50,7 @@ struct GemmEpilogue {
   int ld_acc = 0;
 };
 
+const char* pw_gemm_kernel_name(int m, int n);
 int launch_pw_gemm(const float* a, int lda, const float* w, float* c, int ldc, int m, int n, int k,
                    const GemmEpilogue& epi, hipStream_t stream);
 
@@ -57,6 +58,7 @@ int launch_pw_gemm(const float* a, int lda, const float* w, float* c, int ldc, i
 int launch_dw3x3(const float* in, const float* w, const float* bias, float* out, int batch, int h,
                  int wdt, int c, int stride, hipStream_t stream);
 bool ir_fused_supported(int cin, int cout, int stride);
+const char* ir_fused_kernel_name(int cin, int cout, int stride);
 int launch_ir_fused(const float* in, int ld_in, const float* w1, const float* b1, const float* wd,
                     const float* bd, const float* w2, const float* b2, float* out, int ld_out,
                     int batch, int h, int w, int cin, int cout, int stride, int res,

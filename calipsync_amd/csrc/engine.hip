@@ -169,6 +169,10 @@ struct Arena {
       p += (x.per_frame * batch + 63) / 64 * 64;
     }
   }
+  // view of frames [b0, ...) of an arena bound for the whole batch (every buffer is frame-major)
+  void slice(int b0) {
+    for (auto& x : b) x.p += x.per_frame * (int64_t)b0;
+  }
   float* operator[](Id i) const { return b[i].p; }
 };
 
@@ -178,10 +182,18 @@ struct casync_engine {
   int device = 0;
   const float* w = nullptr;  // packed weights on the device
   float* owned = nullptr;
-  // second stream for the audio encoder, which is independent of the face encoder until the
-  // fusion MLP (module/unet.py:315-321): forked/joined with events inside casync_forward
-  hipStream_t aux = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // second stream per lane for the audio encoder, which is independent of the face encoder until
+  // the fusion MLP (module/unet.py:315-321): forked/joined with events inside casync_forward
+  // Lanes: the batch is cut into kMaxLanes contiguous sub-batches that run concurrently, lane 0
+  // on the caller's stream, the others on engine-owned streams, so one lane's memory-bound
+  // kernels and kernel tails overlap another lane's MFMA-bound GEMMs.  Every lane also forks
+  // its audio encoder onto its own second stream.
+  static constexpr int kMaxLanes = 4;
+  hipStream_t lane_s[kMaxLanes] = {};   // [0] unused (caller's stream)
+  hipStream_t aux[kMaxLanes] = {};
+  hipEvent_t ev_fork[kMaxLanes] = {}, ev_join[kMaxLanes] = {}, ev_done[kMaxLanes] = {};
+  hipEvent_t ev_start = nullptr;
+  bool streams_ready = false;
   const float* W(const std::string& name) const { return w + layout().off(name); }
 };
 
@@ -196,7 +208,7 @@ struct Runner {
   int status = CASYNC_OK;
 
   template <class F>
-  void run(const char* name, double flops, double bytes, F&& f) {
+  void run(const char* name, const char* kernel, double flops, double bytes, F&& f) {
     if (status != CASYNC_OK) return;
     if (profile) {
       hipEvent_t a, b;
@@ -210,6 +222,7 @@ struct Runner {
       casync_kernel_time t;
       memset(&t, 0, sizeof(t));
       strncpy(t.name, name, sizeof(t.name) - 1);
+      strncpy(t.kernel, kernel, sizeof(t.kernel) - 1);
       t.flops = flops;
       t.bytes = bytes;
       rec.push_back(t);
@@ -252,7 +265,7 @@ struct Plan {
     if (epi.pre_res) bytes += 4.0 * m * n;
     if (epi.post_res) bytes += 4.0 * m * n;
     if (epi.acc_out) bytes += 8.0 * m * n;
-    r.run(tag.c_str(), 2.0 * m * n * k, bytes,
+    r.run(tag.c_str(), pw_gemm_kernel_name((int)m, n), 2.0 * m * n * k, bytes,
           [&] { return launch_pw_gemm(a, lda, w, c, ldc, (int)m, n, k, epi, r.s); });
   }
 
@@ -264,7 +277,7 @@ struct Plan {
     if (fuse_ir && !extra && b.hw_in >= fuse_min_hw && ir_fused_supported(b.cin, b.cout, b.stride)) {
       const double flops = 2.0 * (m_in * (double)b.cin * b.cexp() + 9.0 * m_out * b.cexp() +
                                   (double)m_out * b.cexp() * b.cout);
-      r.run((p + ".fused").c_str(), flops, 4.0 * (m_in * (double)b.cin + (double)m_out * b.cout), [&] {
+      r.run((p + ".fused").c_str(), ir_fused_kernel_name(b.cin, b.cout, b.stride), flops, 4.0 * (m_in * (double)b.cin + (double)m_out * b.cout), [&] {
         return launch_ir_fused(in, ld_in, e.W(p + ".pw1.w"), e.W(p + ".pw1.b"), e.W(p + ".dw.w"),
                                e.W(p + ".dw.b"), e.W(p + ".pw2.w"), e.W(p + ".pw2.b"), out, ld_out, B,
                                b.hw_in, b.hw_in, b.cin, b.cout, b.stride, b.res, r.s);
@@ -274,7 +287,7 @@ struct Plan {
     GemmEpilogue ep1;
     ep1.act = 1;
     gemm(p + ".pw1", in, ld_in, p + ".pw1.w", e1, b.cexp(), m_in, b.cexp(), b.cin, ep1);
-    r.run((p + ".dw").c_str(), 2.0 * 9 * m_out * b.cexp(), 4.0 * (m_in + m_out) * b.cexp(), [&] {
+    r.run((p + ".dw").c_str(), b.stride == 1 ? "dw3x3_kernel<1, 4>" : "dw3x3_kernel<2, 2>", 2.0 * 9 * m_out * b.cexp(), 4.0 * (m_in + m_out) * b.cexp(), [&] {
       return launch_dw3x3(e1, e.W(p + ".dw.w"), e.W(p + ".dw.b"), e2, B, b.hw_in, b.hw_in, b.cexp(),
                           b.stride, r.s);
     });
@@ -306,11 +319,11 @@ struct Plan {
     }
     // ---------------- audio encoder (module/unet.py:177-194)
     float *AE1 = ar[A::AE1], *AE2 = ar[A::AE2];
-    r.run("audio.nchw_to_nhwc", 0, 8.0 * B * 32768,
+    r.run("audio.nchw_to_nhwc", "nchw_to_nhwc_kernel", 0, 8.0 * B * 32768,
           [&] { return launch_nchw_to_nhwc(audio, ar[A::A0], B, 32, 1024, r.s); });
     ir(kAudio[0], ar[A::A0], 32, ar[A::AC1], 64, AE1, AE2);
     ir(kAudio[1], ar[A::AC1], 64, ar[A::AC2], 128, AE1, AE2);
-    r.run("audio.conv3.im2col", 0, 4.0 * B * (131072 + 256 * 1152), [&] {
+    r.run("audio.conv3.im2col", "im2col3x3_kernel", 0, 4.0 * B * (131072 + 256 * 1152), [&] {
       return launch_im2col3x3(ar[A::AC2], ar[A::IM], B, 32, 32, 128, 2, 1, r.s);
     });
     {
@@ -319,7 +332,7 @@ struct Plan {
       gemm("audio.conv3", ar[A::IM], 1152, "audio_model.conv3.w", ar[A::AC3], 256, (long long)B * 256, 256, 1152, ep);
     }
     ir(kAudio[2], ar[A::AC3], 256, ar[A::AC4], 256, AE1, AE2);
-    r.run("audio.conv5.im2col", 0, 4.0 * B * (65536 + 100 * 2304), [&] {
+    r.run("audio.conv5.im2col", "im2col3x3_kernel", 0, 4.0 * B * (65536 + 100 * 2304), [&] {
       return launch_im2col3x3(ar[A::AC4], ar[A::IM], B, 16, 16, 256, 2, 3, r.s);
     });
     {
@@ -339,7 +352,7 @@ struct Plan {
       r.s = main_s;
     }
     // ---------------- face encoder (module/unet.py:315-319)
-    r.run("inc", 2.0 * B * 25600 * (72 + 108 + 384), 4.0 * B * 25600 * (6 + 32), [&] {
+    r.run("inc", "inc_kernel", 2.0 * B * 25600 * (72 + 108 + 384), 4.0 * B * 25600 * (6 + 32), [&] {
       return launch_inc(x, e.W("inc.inconv.0.fused"), ar[A::CAT4] + 32, 64, B, r.s);
     });
     struct Skip { float* p; int ld; };
@@ -376,7 +389,7 @@ struct Plan {
       gemm(p + ".p1", prev, 1024, p + ".p1.w", ar[A::P1], 512, M10, 512, 1024, GemmEpilogue());
       gemm(p + ".q", ar[A::P1], 512, p + ".q.w", ar[A::Q], 64, M10, 64, 512, GemmEpilogue());
       const float* kv = ar[A::KV] + i * kKV;
-      r.run((p + ".attn").c_str(), 2.0 * M10 * 100 * (64 + 512), 4.0 * M10 * (64 + kKV + 1024), [&] {
+      r.run((p + ".attn").c_str(), "cross_attention_kernel", 2.0 * M10 * 100 * (64 + 512), 4.0 * M10 * (64 + kKV + 1024), [&] {
         return launch_cross_attention(ar[A::Q], 64, kv, kBlocks * kKV, kv + 64, kBlocks * kKV, ar[A::P1],
                                       512, e.W(p + ".gamma"), ar[A::AO], 512, B, r.s);
       });
@@ -408,7 +421,7 @@ struct Plan {
     int hw = 10, c = 256;
     for (int i = 0; i < 4; ++i) {
       const int cc = 2 * c;  // concat width
-      r.run(("up" + std::to_string(i + 1) + ".bilinear").c_str(), 0, 4.0 * B * hw * hw * c * 5, [&] {
+      r.run(("up" + std::to_string(i + 1) + ".bilinear").c_str(), "upsample2x_kernel", 0, 4.0 * B * hw * hw * c * 5, [&] {
         return launch_upsample2x(lo, cat[i], cc, B, hw, hw, c, r.s);
       });
       ir(kUp[i][0], cat[i], cc, T0, kUp[i][0].cout, E1, E2);
@@ -418,7 +431,7 @@ struct Plan {
       c = kUp[i][1].cout;
     }
     // ---------------- head (module/unet.py:342-344)
-    r.run("outc", 2.0 * B * 25600 * 96, 4.0 * B * 25600 * 35, [&] {
+    r.run("outc", "outc_kernel", 2.0 * B * 25600 * 96, 4.0 * B * 25600 * 35, [&] {
       return launch_outc(ar[A::U4], 32, e.W("outc.w"), e.W("outc.b"), out, B, r.s);
     });
   }
@@ -481,11 +494,15 @@ int casync_create(int device_id, casync_handle* out) {
 
 void casync_destroy(casync_handle h) {
   if (!h) return;
-  if (h->aux) {
-    (void)hipStreamSynchronize(h->aux);
-    (void)hipStreamDestroy(h->aux);
-    (void)hipEventDestroy(h->ev_fork);
-    (void)hipEventDestroy(h->ev_join);
+  if (h->streams_ready) {
+    for (int l = 0; l < casync_engine::kMaxLanes; ++l) {
+      if (h->lane_s[l]) { (void)hipStreamSynchronize(h->lane_s[l]); (void)hipStreamDestroy(h->lane_s[l]); }
+      if (h->aux[l]) { (void)hipStreamSynchronize(h->aux[l]); (void)hipStreamDestroy(h->aux[l]); }
+      if (h->ev_fork[l]) (void)hipEventDestroy(h->ev_fork[l]);
+      if (h->ev_join[l]) (void)hipEventDestroy(h->ev_join[l]);
+      if (h->ev_done[l]) (void)hipEventDestroy(h->ev_done[l]);
+    }
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
   }
   if (h->owned) {
     (void)hipSetDevice(h->device);
@@ -514,26 +531,56 @@ int casync_load_weights_device(casync_handle h, const float* packed_dev, int64_t
   return CASYNC_OK;
 }
 
+static int ensure_streams(casync_handle h) {
+  if (h->streams_ready) return CASYNC_OK;
+  // created lazily on the caller's current device (== h->device)
+  CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
+  for (int l = 0; l < casync_engine::kMaxLanes; ++l) {
+    if (l) CASYNC_CHECK_HIP(hipStreamCreateWithFlags(&h->lane_s[l], hipStreamNonBlocking));
+    CASYNC_CHECK_HIP(hipStreamCreateWithFlags(&h->aux[l], hipStreamNonBlocking));
+    CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork[l], hipEventDisableTiming));
+    CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming));
+    CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_done[l], hipEventDisableTiming));
+  }
+  h->streams_ready = true;
+  return CASYNC_OK;
+}
+
 int casync_forward(casync_handle h, const float* x, const float* a, float* out, int batch, void* ws,
                    int64_t ws_bytes, casync_stream stream) {
   int st = check_forward_args(h, x, a, out, batch, ws, ws_bytes);
   if (st != CASYNC_OK) return st;
-  Runner r;
-  r.s = (hipStream_t)stream;
-  Plan p{*h, Arena(), r, batch};
-  p.ar.bind(ws, batch);
-  if (env_int("CASYNC_OVERLAP", 1)) {
-    if (!h->aux) {  // lazily, on the caller's current device (== h->device)
-      CASYNC_CHECK_HIP(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
-      CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-      CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    }
-    p.aux = h->aux;
-    p.ev_fork = h->ev_fork;
-    p.ev_join = h->ev_join;
+  hipStream_t caller = (hipStream_t)stream;
+  const bool overlap = env_int("CASYNC_OVERLAP", 1) != 0;
+  int lanes = env_int("CASYNC_LANES", 2);
+  lanes = lanes < 1 ? 1 : (lanes > casync_engine::kMaxLanes ? casync_engine::kMaxLanes : lanes);
+  if (batch < 2 * lanes) lanes = 1;  // tiny batches: not worth cutting
+  if (overlap || lanes > 1) {
+    st = ensure_streams(h);
+    if (st != CASYNC_OK) return st;
   }
-  p.forward(x, a, out);
-  return r.status;
+  if (lanes > 1) CASYNC_CHECK_HIP(hipEventRecord(h->ev_start, caller));
+  int b0 = 0;
+  for (int l = 0; l < lanes; ++l) {
+    const int bl = batch / lanes + (l < batch % lanes ? 1 : 0);
+    Runner r;
+    r.s = l == 0 ? caller : h->lane_s[l];
+    if (l) CASYNC_CHECK_HIP(hipStreamWaitEvent(r.s, h->ev_start, 0));
+    Plan p{*h, Arena(), r, bl};
+    p.ar.bind(ws, batch);
+    p.ar.slice(b0);
+    if (overlap) {
+      p.aux = h->aux[l];
+      p.ev_fork = h->ev_fork[l];
+      p.ev_join = h->ev_join[l];
+    }
+    p.forward(x + (size_t)b0 * 6 * 160 * 160, a + (size_t)b0 * 32 * 32 * 32, out + (size_t)b0 * 3 * 160 * 160);
+    if (r.status != CASYNC_OK) return r.status;
+    if (l) CASYNC_CHECK_HIP(hipEventRecord(h->ev_done[l], r.s));
+    b0 += bl;
+  }
+  for (int l = 1; l < lanes; ++l) CASYNC_CHECK_HIP(hipStreamWaitEvent(caller, h->ev_done[l], 0));
+  return CASYNC_OK;
 }
 
 int casync_profile_forward(casync_handle h, const float* x, const float* a, float* out, int batch,

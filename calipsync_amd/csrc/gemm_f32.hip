@@ -37,49 +37,53 @@ constexpr size_t gemm_lds_bytes() {
 }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void pw_gemm_f32_kernel(const float* __restrict__ A, int lda,
+__global__ __launch_bounds__(64 * WM * WN) void pw_gemm_f32_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ W,
                                                           float* __restrict__ C, int ldc, int M,
                                                           int N, int K, int n_ntiles, int nwg,
                                                           GemmEpilogue epi) {
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int NT = 64 * WM * WN;     // threads per workgroup
+  constexpr int RPS = NT / 8;          // rows staged per pass (8 lanes per 128-B row chunk)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int A_PASS = BM / 32, B_PASS = BN / 32;
+  constexpr int A_PASS = BM / RPS, B_PASS = BN / RPS;
+  static_assert(BM % RPS == 0 && BN % RPS == 0, "tile rows must be a multiple of the staging pass");
   constexpr int LDC_S = BN + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                    // [2][BM][LDS_LD]
   float* Bs = smem + 2 * BM * LDS_LD;  // [2][BN][LDS_LD]
   float* Cs = smem;                    // [BM][BN+4], epilogue only
 
-  // XCD-aware tile order: blocks b, b+8, ... share an XCD (round-robin dispatch); give each
-  // XCD a contiguous run of tiles so the N-tiles of one M-panel hit the same L2.  Bijective
-  // for any grid size.  Speed only -- never correctness.
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int mt = bid / n_ntiles, nt = bid - mt * n_ntiles;
-  const int m0 = mt * BM, n0 = nt * BN;
-
   const int tid = threadIdx.x;
   const int lrow = tid >> 3, lc4 = (tid & 7) * 4;  // staging: 8 lanes cover one 128-B row chunk
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave - wm * WN;
   const int r32 = lane & 31, kh = lane >> 5;
+  const int nk = K / BK;
 
   f32x4 ra[A_PASS], rb[B_PASS];
   const float* a_ptr[A_PASS];
   const float* b_ptr[B_PASS];
-#pragma unroll
-  for (int p = 0; p < A_PASS; ++p) {
-    int row = m0 + lrow + 32 * p;
-    row = row < M ? row : M - 1;  // tail rows re-read the last valid row; never stored
-    a_ptr[p] = A + (size_t)row * lda + lc4;
-  }
-#pragma unroll
-  for (int p = 0; p < B_PASS; ++p) b_ptr[p] = W + (size_t)(n0 + lrow + 32 * p) * K + lc4;
 
+  // XCD-aware tile order: workgroups b, b+8, ... share an XCD (round-robin dispatch); give each
+  // XCD a contiguous run of tiles so the N-tiles of one M-panel hit the same L2.  Bijective
+  // for any tile count.  Speed only -- never correctness.
+  auto tile_origin = [&](int t, int& m0, int& n0) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int mt = bid / n_ntiles;
+    m0 = mt * BM;
+    n0 = (bid - mt * n_ntiles) * BN;
+  };
+  auto set_ptrs = [&](int m0, int n0) {
+#pragma unroll
+    for (int p = 0; p < A_PASS; ++p) {
+      int row = m0 + lrow + RPS * p;
+      row = row < M ? row : M - 1;  // tail rows re-read the last valid row; never stored
+      a_ptr[p] = A + (size_t)row * lda + lc4;
+    }
+#pragma unroll
+    for (int p = 0; p < B_PASS; ++p) b_ptr[p] = W + (size_t)(n0 + lrow + RPS * p) * K + lc4;
+  };
   auto gload = [&](int kt) {
 #pragma unroll
     for (int p = 0; p < A_PASS; ++p) ra[p] = *reinterpret_cast<const f32x4*>(a_ptr[p] + kt * BK);
@@ -89,93 +93,114 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_kernel(const float* __restric
   auto sstore = [&](int buf) {
 #pragma unroll
     for (int p = 0; p < A_PASS; ++p)
-      *reinterpret_cast<f32x4*>(As + (buf * BM + lrow + 32 * p) * LDS_LD + lc4) = ra[p];
+      *reinterpret_cast<f32x4*>(As + (buf * BM + lrow + RPS * p) * LDS_LD + lc4) = ra[p];
 #pragma unroll
     for (int p = 0; p < B_PASS; ++p)
-      *reinterpret_cast<f32x4*>(Bs + (buf * BN + lrow + 32 * p) * LDS_LD + lc4) = rb[p];
+      *reinterpret_cast<f32x4*>(Bs + (buf * BN + lrow + RPS * p) * LDS_LD + lc4) = rb[p];
   };
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // epilogue constants that do not depend on the tile row
+  constexpr int TPR = BN / 4;          // threads per output row
+  constexpr int RPP = NT / TPR;        // rows per pass
+  const int c4 = (tid % TPR) * 4, rr = tid / TPR;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
 
-  const int nk = K / BK;
+  // Persistent over tiles: the first k-tile of the NEXT tile is fetched into registers while
+  // the last k-tile of this one computes, so its HBM latency hides under the MFMAs and the
+  // epilogue instead of being exposed once per tile.
+  int tile = blockIdx.x;
+  int m0, n0;
+  tile_origin(tile, m0, n0);
+  set_ptrs(m0, n0);
   gload(0);
-  sstore(0);
-  __syncthreads();
+  for (; tile < nwg; tile += gridDim.x) {
+    sstore(0);
+    __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);  // in flight under the MFMAs below
-    const float* a_base = As + (buf * BM + wm * (BM / WM) + r32) * LDS_LD + 4 * kh;
-    const float* b_base = Bs + (buf * BN + wn * (BN / WN) + r32) * LDS_LD + 4 * kh;
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-      f32x4 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        fa[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * LDS_LD + 8 * g);
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        fb[j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * LDS_LD + 8 * g);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int next = tile + gridDim.x;
+    int m0n = 0, n0n = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) {
+        gload(kt + 1);  // in flight under the MFMAs below
+      } else if (next < nwg) {
+        tile_origin(next, m0n, n0n);
+        set_ptrs(m0n, n0n);
+        gload(0);       // next tile's first k-tile
+      }
+      const float* a_base = As + (buf * BM + wm * (BM / WM) + r32) * LDS_LD + 4 * kh;
+      const float* b_base = Bs + (buf * BN + wn * (BN / WN) + r32) * LDS_LD + 4 * kh;
+#pragma unroll
+      for (int g = 0; g < BK / 8; ++g) {
+        f32x4 fa[TM], fb[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
+          fa[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * LDS_LD + 8 * g);
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) sstore(buf ^ 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue 1: accumulators -> LDS tile (row-major) ----
+        for (int j = 0; j < TN; ++j)
+          fb[j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * LDS_LD + 8 * g);
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float* cbase = Cs + (wm * (BM / WM) + i * 32 + 4 * kh) * LDC_S + wn * (BN / WN) + j * 32 + r32;
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) cbase[((r & 3) + 8 * (r >> 2)) * LDC_S] = acc[i][j][r];
-    }
-  __syncthreads();
-
-  // ---- epilogue 2: float4 rows: bias, residuals, activation, coalesced stores ----
-  constexpr int TPR = BN / 4;          // threads per output row
-  constexpr int RPP = 256 / TPR;       // rows per pass
-  const int c4 = (tid % TPR) * 4, rr = tid / TPR;
-  const int n = n0 + c4;
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
-  const f32x4 bias = epi.bias ? *reinterpret_cast<const f32x4*>(epi.bias + n) : zero;
-  const f32x4 pscale = epi.pre_scale ? *reinterpret_cast<const f32x4*>(epi.pre_scale + n) : one;
-  const f32x4 as = epi.aff_s ? *reinterpret_cast<const f32x4*>(epi.aff_s + n) : one;
-  const f32x4 at = epi.aff_s ? *reinterpret_cast<const f32x4*>(epi.aff_t + n) : zero;
-#pragma unroll 4
-  for (int p = 0; p < BM / RPP; ++p) {
-    const int row = rr + RPP * p, m = m0 + row;
-    if (m >= M) break;
-    f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC_S + c4) + bias;
-    if (epi.pre_res) v += pscale * *reinterpret_cast<const f32x4*>(epi.pre_res + (size_t)m * epi.ld_pre + n);
-    if (epi.act) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
-    if (epi.post_res) v += *reinterpret_cast<const f32x4*>(epi.post_res + (size_t)m * epi.ld_post + n);
-    if (epi.aff_s && !epi.aff_on_acc) {
-      v = v * as + at;
-      v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w);
-    }
-    *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n) = v;
-    if (epi.acc_out) {
-      f32x4 s = *reinterpret_cast<const f32x4*>(epi.acc_in + (size_t)m * epi.ld_acc + n) + v;
-      if (epi.aff_s && epi.aff_on_acc) {
-        s = s * as + at;
-        s.x = lrelu(s.x); s.y = lrelu(s.y); s.z = lrelu(s.z); s.w = lrelu(s.w);
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
       }
-      *reinterpret_cast<f32x4*>(epi.acc_out + (size_t)m * epi.ld_acc + n) = s;
+      if (kt + 1 < nk) sstore(buf ^ 1);
+      __syncthreads();
     }
+
+    // ---- epilogue 1: accumulators -> LDS tile (row-major) ----
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float* cbase = Cs + (wm * (BM / WM) + i * 32 + 4 * kh) * LDC_S + wn * (BN / WN) + j * 32 + r32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cbase[((r & 3) + 8 * (r >> 2)) * LDC_S] = acc[i][j][r];
+      }
+    __syncthreads();
+
+    // ---- epilogue 2: float4 rows: bias, residuals, activation, coalesced stores ----
+    const int n = n0 + c4;
+    const f32x4 bias = epi.bias ? *reinterpret_cast<const f32x4*>(epi.bias + n) : zero;
+    const f32x4 pscale = epi.pre_scale ? *reinterpret_cast<const f32x4*>(epi.pre_scale + n) : one;
+    const f32x4 as = epi.aff_s ? *reinterpret_cast<const f32x4*>(epi.aff_s + n) : one;
+    const f32x4 at = epi.aff_s ? *reinterpret_cast<const f32x4*>(epi.aff_t + n) : zero;
+#pragma unroll 4
+    for (int p = 0; p < BM / RPP; ++p) {
+      const int row = rr + RPP * p, m = m0 + row;
+      if (m >= M) break;
+      f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC_S + c4) + bias;
+      if (epi.pre_res) v += pscale * *reinterpret_cast<const f32x4*>(epi.pre_res + (size_t)m * epi.ld_pre + n);
+      if (epi.act) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
+      if (epi.post_res) v += *reinterpret_cast<const f32x4*>(epi.post_res + (size_t)m * epi.ld_post + n);
+      if (epi.aff_s && !epi.aff_on_acc) {
+        v = v * as + at;
+        v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w);
+      }
+      *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n) = v;
+      if (epi.acc_out) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(epi.acc_in + (size_t)m * epi.ld_acc + n) + v;
+        if (epi.aff_s && epi.aff_on_acc) {
+          s = s * as + at;
+          s.x = lrelu(s.x); s.y = lrelu(s.y); s.z = lrelu(s.z); s.w = lrelu(s.w);
+        }
+        *reinterpret_cast<f32x4*>(epi.acc_out + (size_t)m * epi.ld_acc + n) = s;
+      }
+    }
+    __syncthreads();  // the C tile aliases the staging buffers the next tile is about to fill
+    m0 = m0n;
+    n0 = n0n;
   }
 }
 
@@ -193,7 +218,12 @@ int launch_cfg(const float* a, int lda, const float* w, float* c, int ldc, int m
   const int n_mtiles = (m + BM - 1) / BM, n_ntiles = n / BN;
   const long long nwg = (long long)n_mtiles * n_ntiles;
   CASYNC_REQUIRE(nwg < (1ll << 31), "gemm grid too large");
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, a, lda, w, c, ldc, m, n, k,
+  // persistent grid: as many workgroups as can be resident (LDS-limited), each walks tiles
+  static const int persist = [] { const char* v = getenv("CASYNC_GEMM_PERSIST"); return v ? atoi(v) : 1; }();
+  constexpr int per_cu = (int)(160 * 1024 / lds) < 8 ? (int)(160 * 1024 / lds) : 8;
+  const long long cap = 256ll * (per_cu < 1 ? 1 : per_cu);
+  const unsigned grid = (unsigned)(persist && nwg > cap ? cap : nwg);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds, stream, a, lda, w, c, ldc, m, n, k,
                      n_ntiles, (int)nwg, epi);
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
@@ -202,17 +232,18 @@ int launch_cfg(const float* a, int lda, const float* w, float* c, int ldc, int m
 // Tile choice.  On a 256-CU chip a launch of G workgroups finishes after ceil(G/256) "rounds" of
 // one tile per CU (co-resident tiles share the CU's matrix pipes, so they add, not overlap);
 // pick the tile that minimises rounds x tile area, preferring the larger tile on ties.
-enum Cfg { C128x128 = 0, C128x64, C64x64, C128x32, CFG_COUNT };
+enum Cfg { C128x128 = 0, C128x64, C64x64, C128x32, C64x32, CFG_COUNT };
 
 int pick_cfg(int m, int n) {
   static const int forced = [] { const char* v = getenv("CASYNC_GEMM_CFG"); return v ? atoi(v) : -1; }();
   struct T { Cfg id; int bm, bn; };
-  const T tiles[] = {{C128x128, 128, 128}, {C128x64, 128, 64}, {C64x64, 64, 64}, {C128x32, 128, 32}};
+  const T tiles[] = {{C128x128, 128, 128}, {C128x64, 128, 64}, {C64x64, 64, 64}, {C128x32, 128, 32},
+                     {C64x32, 64, 32}};
   if (forced >= 0 && forced < CFG_COUNT && n % tiles[forced].bn == 0) return forced;
   int best = -1;
   double best_cost = 0;
   for (const T& t : tiles) {
-    if (n % t.bn) continue;
+    if (n % t.bn || t.id == C64x32) continue;   // the 2-wave tile is for experiments only (slower)
     const long long g = (long long)((m + t.bm - 1) / t.bm) * (n / t.bn);
     const double rounds = (double)((g + 255) / 256);
     // small per-round overhead so that, when rounds x area ties, fewer / larger tiles win
@@ -223,6 +254,17 @@ int pick_cfg(int m, int n) {
 }
 
 }  // namespace
+
+// Name of the kernel instance launch_pw_gemm() will pick (as rocprofv3 prints it).
+const char* pw_gemm_kernel_name(int m, int n) {
+  switch (pick_cfg(m, n)) {
+    case C128x128: return "pw_gemm_f32_kernel<128, 128, 2, 2>";
+    case C128x64: return "pw_gemm_f32_kernel<128, 64, 4, 1>";
+    case C64x64: return "pw_gemm_f32_kernel<64, 64, 2, 2>";
+    case C64x32: return "pw_gemm_f32_kernel<64, 32, 2, 1>";
+    default: return "pw_gemm_f32_kernel<128, 32, 4, 1>";
+  }
+}
 
 int launch_pw_gemm(const float* a, int lda, const float* w, float* c, int ldc, int m, int n, int k,
                    const GemmEpilogue& epi, hipStream_t stream) {
@@ -242,6 +284,7 @@ int launch_pw_gemm(const float* a, int lda, const float* w, float* c, int ldc, i
     case C128x128: return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream);
     case C128x64: return launch_cfg<128, 64, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream);
     case C64x64: return launch_cfg<64, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream);
+    case C64x32: return launch_cfg<64, 32, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream);
     default: return launch_cfg<128, 32, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream);
   }
 }

@@ -367,6 +367,12 @@ bool ir_fused_supported(int cin, int cout, int stride) {
   return false;
 }
 
+const char* ir_fused_kernel_name(int cin, int cout, int stride) {
+  static thread_local char buf[64];
+  snprintf(buf, sizeof(buf), "ir_fused_kernel<%d, %d, %d, %d, 16>", cin, 2 * cin, cout, stride);
+  return buf;
+}
+
 int launch_ir_fused(const float* in, int ld_in, const float* w1, const float* b1, const float* wd,
                     const float* bd, const float* w2, const float* b2, float* out, int ld_out,
                     int batch, int h, int w, int cin, int cout, int stride, int res,

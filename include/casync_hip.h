@@ -88,7 +88,8 @@ int64_t casync_tap(casync_handle h, const char* name, int batch, void* workspace
 /* Per-kernel timing of one forward (HIP events around every launch on
  * `stream`; synchronises).  Writes up to `cap` entries; returns the count.  */
 typedef struct {
-  char  name[48];
+  char  name[48];     /* plan step, e.g. "up4.conv.double_conv.0.fused"      */
+  char  kernel[48];   /* HIP kernel instance as rocprofv3 names it           */
   float ms;
   double flops;       /* algorithmic flops of this launch                   */
   double bytes;       /* algorithmic bytes (inputs read once + outputs)     */

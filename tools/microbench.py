@@ -62,6 +62,7 @@ def bench_ir(args):
 
 
 GEMM_SHAPES = [  # (name, rows per frame, N, K)
+    ("sq4096", 64, 4096, 4096), ("big", 400, 1024, 1024),
     ("p1", 100, 512, 1024), ("b1", 100, 1024, 512), ("fc", 100, 1024, 1024), ("kv", 100, 2304, 512),
     ("fuse.pw1", 100, 2048, 1024), ("fuse.pw2", 100, 512, 2048), ("q", 100, 64, 512),
     ("conv5", 100, 512, 2304), ("conv3", 256, 256, 1152), ("d4.pw1", 400, 512, 256), ("u1.pw1", 400, 1024, 512),
