@@ -59,6 +59,11 @@ int launch_dw3x3(const float* in, const float* w, const float* bias, float* out,
                  int wdt, int c, int stride, hipStream_t stream);
 bool ir_fused_supported(int cin, int cout, int stride);
 const char* ir_fused_kernel_name(int cin, int cout, int stride);
+bool ir_fused_up_supported(int cin, int cout);
+int launch_ir_fused_up(const float* lo, int ld_lo, int c_lo, const float* in, int ld_in, const float* w1,
+                       const float* b1, const float* wd, const float* bd, const float* w2,
+                       const float* b2, float* out, int ld_out, int batch, int h, int w, int cin,
+                       int cout, hipStream_t stream);
 int launch_ir_fused(const float* in, int ld_in, const float* w1, const float* b1, const float* wd,
                     const float* bd, const float* w2, const float* b2, float* out, int ld_out,
                     int batch, int h, int w, int cin, int cout, int stride, int res,

@@ -254,6 +254,7 @@ struct Plan {
   hipStream_t aux = nullptr;          // engine's second stream (null = no overlap)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool fuse_ir = env_int("CASYNC_FUSE_IR", 1) != 0;      // A/B switch for the fused IR kernel
+  bool fuse_up = env_int("CASYNC_FUSE_UP", 1) != 0;      // fold the bilinear upsample into up3/up4
   int fuse_min_hw = env_int("CASYNC_FUSE_MIN_HW", 32);   // fuse stages at least this large
 
   // GEMM wrapper with work accounting (algorithmic bytes: A + C once, W once)
@@ -421,10 +422,23 @@ struct Plan {
     int hw = 10, c = 256;
     for (int i = 0; i < 4; ++i) {
       const int cc = 2 * c;  // concat width
-      r.run(("up" + std::to_string(i + 1) + ".bilinear").c_str(), "upsample2x_kernel", 0, 4.0 * B * hw * hw * c * 5, [&] {
-        return launch_upsample2x(lo, cat[i], cc, B, hw, hw, c, r.s);
-      });
-      ir(kUp[i][0], cat[i], cc, T0, kUp[i][0].cout, E1, E2);
+      const IR& b0 = kUp[i][0];
+      if (fuse_ir && fuse_up && 2 * hw >= fuse_min_hw && ir_fused_up_supported(b0.cin, b0.cout)) {
+        // bilinear x2 folded into the fused block's input load: up(x) is never materialised
+        const std::string p = b0.prefix;
+        const double m = (double)B * 4 * hw * hw;
+        r.run((p + ".upfused").c_str(), "ir_fused_kernel<up>", 2.0 * m * (b0.cin * b0.cexp() + 9.0 * b0.cexp() + b0.cexp() * b0.cout),
+              4.0 * (m / 4 * c + m * c + m * b0.cout), [&] {
+                return launch_ir_fused_up(lo, c, c, cat[i], cc, e.W(p + ".pw1.w"), e.W(p + ".pw1.b"),
+                                          e.W(p + ".dw.w"), e.W(p + ".dw.b"), e.W(p + ".pw2.w"),
+                                          e.W(p + ".pw2.b"), T0, b0.cout, B, 2 * hw, 2 * hw, b0.cin, b0.cout, r.s);
+              });
+      } else {
+        r.run(("up" + std::to_string(i + 1) + ".bilinear").c_str(), "upsample2x_kernel", 0, 4.0 * B * hw * hw * c * 5, [&] {
+          return launch_upsample2x(lo, cat[i], cc, B, hw, hw, c, r.s);
+        });
+        ir(b0, cat[i], cc, T0, b0.cout, E1, E2);
+      }
       ir(kUp[i][1], T0, kUp[i][1].cin, uo[i], kUp[i][1].cout, E1, E2);
       lo = uo[i];
       hw *= 2;
@@ -589,16 +603,26 @@ int casync_profile_forward(casync_handle h, const float* x, const float* a, floa
   int st = check_forward_args(h, x, a, out, batch, ws, ws_bytes);
   if (st != CASYNC_OK) return st;
   CASYNC_REQUIRE(res && cap > 0, "profile_forward: null result buffer");
-  Runner r;
-  r.s = (hipStream_t)stream;
-  r.profile = true;
-  Plan p{*h, Arena(), r, batch};
-  p.ar.bind(ws, batch);
-  p.forward(x, a, out);
-  r.finish();
-  if (r.status != CASYNC_OK) return r.status;
-  const int n = (int)r.rec.size() < cap ? (int)r.rec.size() : cap;
-  for (int i = 0; i < n; ++i) res[i] = r.rec[i];
+  // Same launches (same per-lane sub-batches, hence the same kernel instances and grids) as
+  // casync_forward, but serialised on the caller's stream with an event pair around each.
+  int lanes = env_int("CASYNC_LANES", 2);
+  lanes = lanes < 1 ? 1 : (lanes > casync_engine::kMaxLanes ? casync_engine::kMaxLanes : lanes);
+  if (batch < 2 * lanes) lanes = 1;
+  int n = 0, b0 = 0;
+  for (int l = 0; l < lanes; ++l) {
+    const int bl = batch / lanes + (l < batch % lanes ? 1 : 0);
+    Runner r;
+    r.s = (hipStream_t)stream;
+    r.profile = true;
+    Plan p{*h, Arena(), r, bl};
+    p.ar.bind(ws, batch);
+    p.ar.slice(b0);
+    p.forward(x + (size_t)b0 * 6 * 160 * 160, a + (size_t)b0 * 32 * 32 * 32, out + (size_t)b0 * 3 * 160 * 160);
+    r.finish();
+    if (r.status != CASYNC_OK) return r.status;
+    for (size_t i = 0; i < r.rec.size() && n < cap; ++i) res[n++] = r.rec[i];
+    b0 += bl;
+  }
   return n;
 }
 
@@ -662,6 +686,13 @@ int casync_op_ir_fused(const float* in, int ld_in, const float* w1, const float*
                        casync_stream stream) {
   return launch_ir_fused(in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out, batch, h, w, cin, cout, stride,
                          res, (hipStream_t)stream);
+}
+int casync_op_ir_fused_up(const float* lo, int ld_lo, int c_lo, const float* in, int ld_in, const float* w1,
+                          const float* b1, const float* wd, const float* bd, const float* w2,
+                          const float* b2, float* out, int ld_out, int batch, int h, int w, int cin,
+                          int cout, casync_stream stream) {
+  return launch_ir_fused_up(lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out, batch, h, w, cin,
+                            cout, (hipStream_t)stream);
 }
 int casync_op_im2col3x3(const float* in, float* out, int batch, int h, int wdt, int c, int stride,
                         int pad, casync_stream stream) {

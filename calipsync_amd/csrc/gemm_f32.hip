@@ -232,18 +232,18 @@ int launch_cfg(const float* a, int lda, const float* w, float* c, int ldc, int m
 // Tile choice.  On a 256-CU chip a launch of G workgroups finishes after ceil(G/256) "rounds" of
 // one tile per CU (co-resident tiles share the CU's matrix pipes, so they add, not overlap);
 // pick the tile that minimises rounds x tile area, preferring the larger tile on ties.
-enum Cfg { C128x128 = 0, C128x64, C64x64, C128x32, C64x32, CFG_COUNT };
+enum Cfg { C128x128 = 0, C128x64, C64x64, C128x32, C64x32, C64x64W2, CFG_COUNT };
 
 int pick_cfg(int m, int n) {
   static const int forced = [] { const char* v = getenv("CASYNC_GEMM_CFG"); return v ? atoi(v) : -1; }();
   struct T { Cfg id; int bm, bn; };
   const T tiles[] = {{C128x128, 128, 128}, {C128x64, 128, 64}, {C64x64, 64, 64}, {C128x32, 128, 32},
-                     {C64x32, 64, 32}};
+                     {C64x32, 64, 32}, {C64x64W2, 64, 64}};
   if (forced >= 0 && forced < CFG_COUNT && n % tiles[forced].bn == 0) return forced;
   int best = -1;
   double best_cost = 0;
   for (const T& t : tiles) {
-    if (n % t.bn || t.id == C64x32) continue;   // the 2-wave tile is for experiments only (slower)
+    if (n % t.bn || t.id >= C64x32) continue;   // experimental configs: only when forced
     const long long g = (long long)((m + t.bm - 1) / t.bm) * (n / t.bn);
     const double rounds = (double)((g + 255) / 256);
     // small per-round overhead so that, when rounds x area ties, fewer / larger tiles win
@@ -259,9 +259,10 @@ int pick_cfg(int m, int n) {
 const char* pw_gemm_kernel_name(int m, int n) {
   switch (pick_cfg(m, n)) {
     case C128x128: return "pw_gemm_f32_kernel<128, 128, 2, 2>";
-    case C128x64: return "pw_gemm_f32_kernel<128, 64, 4, 1>";
+    case C128x64: return "pw_gemm_f32_kernel<128, 64, 2, 2>";
     case C64x64: return "pw_gemm_f32_kernel<64, 64, 2, 2>";
     case C64x32: return "pw_gemm_f32_kernel<64, 32, 2, 1>";
+    case C64x64W2: return "pw_gemm_f32_kernel<64, 64, 2, 1>";
     default: return "pw_gemm_f32_kernel<128, 32, 4, 1>";
   }
 }
@@ -282,9 +283,10 @@ int launch_pw_gemm(const float* a, int lda, const float* w, float* c, int ldc, i
                  "pw_gemm: residual leading dimensions must be multiples of 4");
   switch (pick_cfg(m, n)) {
     case C128x128: return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream);
-    case C128x64: return launch_cfg<128, 64, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream);
+    case C128x64: return launch_cfg<128, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream);
     case C64x64: return launch_cfg<64, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream);
     case C64x32: return launch_cfg<64, 32, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream);
+    case C64x64W2: return launch_cfg<64, 64, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream);
     default: return launch_cfg<128, 32, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream);
   }
 }

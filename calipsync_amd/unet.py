@@ -227,11 +227,11 @@ class Model(nn.Module):
             self._ensure_weights(dev)
             ws = self._ws(batch, dev)
             out = torch.empty((batch, 3, arch.FACE_HW, arch.FACE_HW), dtype=torch.float32, device=dev)
-            arr = (_lib.KernelTime * 256)()
+            arr = (_lib.KernelTime * 1024)()
             stream = torch.cuda.current_stream(dev).cuda_stream
             n = _lib.check(_lib.load().casync_profile_forward(
                 self._engine, x.contiguous().data_ptr(), audio_feat.contiguous().data_ptr(),
-                out.data_ptr(), batch, ws.data_ptr(), ws.numel(), stream, arr, 256),
+                out.data_ptr(), batch, ws.data_ptr(), ws.numel(), stream, arr, 1024),
                 "casync_profile_forward")
         return [{"name": arr[i].name.decode(), "kernel": arr[i].kernel.decode(), "ms": arr[i].ms, "flops": arr[i].flops,
                  "bytes": arr[i].bytes} for i in range(n)]

@@ -123,6 +123,13 @@ int casync_op_ir_fused(const float* in, int ld_in, const float* w1, const float*
                        const float* wd, const float* bd, const float* w2, const float* b2,
                        float* out, int ld_out, int batch, int h, int w, int cin, int cout,
                        int stride, int res, casync_stream stream);
+/* Decoder variant: the block input is cat([bilinear_x2(lo)[0:c_lo], in[c_lo:cin]]) with the
+ * upsample (align_corners=True) computed while loading -- Up.forward's interpolate + cat +
+ * first InvertedResidual (module/unet.py:90-97) in one kernel.  lo: [B,h/2,w/2,ld_lo].     */
+int casync_op_ir_fused_up(const float* lo, int ld_lo, int c_lo, const float* in, int ld_in,
+                          const float* w1, const float* b1, const float* wd, const float* bd,
+                          const float* w2, const float* b2, float* out, int ld_out, int batch,
+                          int h, int w, int cin, int cout, casync_stream stream);
 /* im2col for the two dense 3x3 stride-2 convs (module/unet.py:161-168):
  * out[B*Ho*Wo][9*C], column order (ky,kx,c).                                */
 int casync_op_im2col3x3(const float* in, float* out, int batch, int h, int wdt, int c,

@@ -231,3 +231,26 @@ def test_ir_fused_rejects_unknown_shape(lib):
     st = lib.casync_op_ir_fused(ptr(z), 48, ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), 48, 1, 4, 4,
                                 48, 48, 1, 0, stream())
     assert st < 0 and b"no instance" in lib.casync_last_error()
+
+
+@pytest.mark.parametrize("prefix,cin,h", [("up4.conv.double_conv.0", 64, 48), ("up3.conv.double_conv.0", 128, 32)])
+def test_ir_fused_with_upsample(lib, recipe_sd, prefix, cin, h):
+    """Up.forward's interpolate + cat + first inverted residual in one kernel vs the oracle."""
+    from oracle import unet_oracle
+    sd = unet_oracle.to_torch(recipe_sd)
+    f = pack.fold(recipe_sd)
+    g = torch.Generator().manual_seed(cin)
+    b, c_lo = 2, cin // 2
+    lo = torch.randn(b, c_lo, h // 2, h // 2, generator=g)
+    skip = torch.randn(b, cin - c_lo, h, h, generator=g)
+    up = F.interpolate(lo, scale_factor=2, mode="bilinear", align_corners=True)
+    ref = unet_oracle.inverted_residual(sd, prefix, torch.cat([up, skip], 1), 1, False)
+    cat = torch.full((b, h, h, cin), 77.0)                   # upsampled half is never materialised
+    cat[..., c_lo:] = skip.permute(0, 2, 3, 1)
+    cat, lod = cat.to(dev()), nhwc(lo)
+    out = torch.empty(b, h, h, 32, device=dev())
+    T = lambda k: torch.from_numpy(f[f"{prefix}.{k}"].astype(np.float32)).contiguous().to(dev())
+    w1, b1, wd, bd, w2, b2 = T("pw1.w"), T("pw1.b"), T("dw.w"), T("dw.b"), T("pw2.w"), T("pw2.b")
+    ok(lib.casync_op_ir_fused_up(ptr(lod), c_lo, c_lo, ptr(cat), cin, ptr(w1), ptr(b1), ptr(wd), ptr(bd), ptr(w2),
+                                 ptr(b2), ptr(out), 32, b, h, h, cin, 32, stream()))
+    assert rel_err(nchw(out), ref) < 5e-6
