@@ -146,9 +146,14 @@ def main():
 
     # ---- per-kernel timing with HIP events on the launch stream (rank 0)
     result = None
+    lanes = int(os.environ.get("CASYNC_LANES", "2"))
     if rank == 0:
         per = {}
         reps = 3
+        # The timed region overlaps `lanes` half-batch lanes (and the audio stream) on the GPU, so
+        # per-kernel durations there are not separable.  The roofline pass therefore replays the
+        # SAME batch with the launches isolated: one lane, one stream, an event pair per launch.
+        os.environ["CASYNC_LANES"] = "1"
         for _ in range(reps):
             for row in net.profile(x, a):
                 c = per.setdefault(row["kernel"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
@@ -162,6 +167,7 @@ def main():
             for r in rows:
                 print(f"  {r['name']:48s} {r['kernel']:38s} {r['ms']:8.3f} ms {r['flops'] / max(r['ms'], 1e-6) / 1e9:8.1f} TF "
                       f"{r['bytes'] / max(r['ms'], 1e-6) / 1e6:8.1f} GB/s", file=sys.stderr)
+        os.environ["CASYNC_LANES"] = str(lanes)
         dom_name, dom = max(per.items(), key=lambda kv: kv[1]["ms"])
         tf = dom["flops"] / dom["ms"] / 1e9
         gbs = dom["bytes"] / dom["ms"] / 1e6
@@ -178,6 +184,8 @@ def main():
             "launches_per_step": dom["n"] // reps,
             "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
             "share_of_step": round(dom["ms"] / sum(c["ms"] for c in per.values()), 3),
+            "measured": "HIP events around every launch, isolated single-lane replay of the same batch "
+                        "(profiles/r1_final_kernel_stats_lanes1.csv is rocprofv3 of that mode)",
         }
         work = arch.work_per_frame()
         fps = world * B * args.steps / dt
@@ -197,7 +205,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"batch={B}/GPU 160x160 fp32 crops + HuBERT windows through Model.forward "
                                    "(BASELINE configs[1]); frames sharded, weights broadcast once",
-                       "global_batch": B * world, "parallelism": f"frames-dp{world}"},
+                       "global_batch": B * world, "parallelism": f"frames-dp{world}",
+                       "lanes_per_gpu": lanes},
             "roofline": roofline,
             "whole_net": {"mfma_frac": round(per_gpu * work["flops"] / (MFMA_F32_PEAK_TF * 1e12), 4),
                           "hbm_frac_canonical": round(per_gpu * work["canonical_bytes_f32"] / (HBM_PEAK_GBS * 1e9), 4),
