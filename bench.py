@@ -33,6 +33,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: f32-input MFMA == f32 vector peak
+MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
 def parse():
@@ -41,6 +42,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="engine activation storage: f32 = parity path (default), bf16 = BASELINE configs[2]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--kernel-table", action="store_true", help="print the per-launch table to stderr")
@@ -112,7 +115,7 @@ def main():
 
     # ---- weights: rank 0 folds + packs, ONE RCCL broadcast, every rank adopts the buffer
     sd_np = recipe.make_state_dict() if rank == 0 else None
-    net = Model(6, "hubert").to(dev)
+    net = Model(6, "hubert", precision="bf16" if args.dtype == "bf16" else "fp32").to(dev)
     if rank == 0:
         net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
     packed = broadcast_packed_weights(net if rank == 0 else None, dev)
@@ -171,15 +174,16 @@ def main():
         dom_name, dom = max(per.items(), key=lambda kv: kv[1]["ms"])
         tf = dom["flops"] / dom["ms"] / 1e9
         gbs = dom["bytes"] / dom["ms"] / 1e6
-        mfma_bound = dom_name.startswith(("pw_gemm_f32_kernel", "ir_fused_kernel")) and \
-            tf / MFMA_F32_PEAK_TF >= gbs / HBM_PEAK_GBS
+        mfma_peak = MFMA_F32_PEAK_TF if args.dtype == "f32" or dom_name.startswith("ir_fused") else MFMA_BF16_PEAK_TF
+        mfma_bound = dom_name.startswith(("pw_gemm_kernel", "ir_fused_kernel")) and \
+            tf / mfma_peak >= gbs / HBM_PEAK_GBS
         roofline = {
             "kernel": dom_name,
             "bound": "mfma" if mfma_bound else "hbm",
             "achieved": round(tf if mfma_bound else gbs, 2),
-            "peak": MFMA_F32_PEAK_TF if mfma_bound else HBM_PEAK_GBS,
+            "peak": mfma_peak if mfma_bound else HBM_PEAK_GBS,
             "unit": "TFLOP/s" if mfma_bound else "GB/s",
-            "frac": round((tf / MFMA_F32_PEAK_TF) if mfma_bound else (gbs / HBM_PEAK_GBS), 4),
+            "frac": round((tf / mfma_peak) if mfma_bound else (gbs / HBM_PEAK_GBS), 4),
             "traffic": None,
             "launches_per_step": dom["n"] // reps,
             "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
@@ -201,10 +205,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.dtype == "f32" else "bf16 (fp32 accumulate; NOT the parity path)",
             "data": "synthetic",
             "config": {"workload": f"batch={B}/GPU 160x160 fp32 crops + HuBERT windows through Model.forward "
-                                   "(BASELINE configs[1]); frames sharded, weights broadcast once",
+                                   f"({'BASELINE configs[1]' if args.dtype == 'f32' else 'bf16 engine, BASELINE configs[2] family'}); "
+                                   "frames sharded, weights broadcast once",
                        "global_batch": B * world, "parallelism": f"frames-dp{world}",
                        "lanes_per_gpu": lanes},
             "roofline": roofline,

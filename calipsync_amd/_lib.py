@@ -30,7 +30,9 @@ _PROTOS = {
     "casync_packed_size": (c_i64, [C.c_int]),
     "casync_packed_total": (c_i64, []),
     "casync_workspace_bytes": (c_i64, [C.c_int]),
+    "casync_workspace_bytes_dt": (c_i64, [C.c_int, C.c_int]),
     "casync_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "casync_create_ex": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "casync_destroy": (None, [C.c_void_p]),
     "casync_load_weights_host": (C.c_int, [C.c_void_p, C.c_void_p, c_i64]),
     "casync_load_weights_device": (C.c_int, [C.c_void_p, c_f32p, c_i64]),
@@ -39,6 +41,7 @@ _PROTOS = {
     "casync_tap": (c_i64, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, c_f32p, c_i64, C.c_void_p]),
     "casync_profile_forward": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_void_p,
                                          c_i64, C.c_void_p, C.POINTER(KernelTime), C.c_int]),
+    "casync_op_set_dtype": (C.c_int, [C.c_int]),
     "casync_op_pw_gemm": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_f32p, c_f32p,
                                     C.c_int, c_f32p, c_f32p, C.c_void_p]),

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcasync_hip.so")
-SOURCES = ["gemm_f32.hip", "ops.hip", "ir_fused.hip", "attention.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "ops.hip", "ir_fused.hip", "attention.hip", "engine.hip"]
 HEADERS = ["common.h", os.path.join("..", "..", "include", "casync_hip.h")]
 
 

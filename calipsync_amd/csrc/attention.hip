@@ -29,10 +29,11 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void cross_attention_kernel(
-    const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
-    const float* __restrict__ v, int ldv, const float* __restrict__ res, int ld_res,
-    const float* __restrict__ gamma, float* __restrict__ out, int ld_out) {
+    const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+    const T* __restrict__ v, int ldv, const T* __restrict__ res, int ld_res,
+    const float* __restrict__ gamma, T* __restrict__ out, int ld_out) {
   __shared__ __attribute__((aligned(16))) float Qs[32 * QLD];
   __shared__ __attribute__((aligned(16))) float Ks[128 * QLD];
   __shared__ __attribute__((aligned(16))) float Ss[32 * SLD];
@@ -48,14 +49,14 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(
     for (int p = 0; p < 2; ++p) {
       const int lr = r + 16 * p, qi = qb * 32 + lr;
       f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (qi < NP) val = *reinterpret_cast<const f32x4*>(q + (row0 + qi) * ldq + c4);
+      if (qi < NP) val = ld4(q + (row0 + qi) * ldq + c4);
       *reinterpret_cast<f32x4*>(Qs + lr * QLD + c4) = val;
     }
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int kr = r + 16 * p;
       f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (kr < NP) val = *reinterpret_cast<const f32x4*>(k + (row0 + kr) * ldk + c4);
+      if (kr < NP) val = ld4(k + (row0 + kr) * ldk + c4);
       *reinterpret_cast<f32x4*>(Ks + kr * QLD + c4) = val;
     }
   }
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   const float* pa = Ss + r32 * SLD + 4 * kh;
-  const float* vb = v + wave * 128 + r32;
+  const T* vb = v + wave * 128 + r32;
 #pragma unroll 1
   for (int g = 0; g < 13; ++g) {  // 13 groups of 8 keys cover 0..103; P is zero past 99
     const f32x4 fa = *reinterpret_cast<const f32x4*>(pa + 8 * g);
@@ -114,10 +115,10 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(
     for (int s = 0; s < 4; ++s) {
       int key = 8 * g + 4 * kh + s;
       key = key < NP ? key : NP - 1;  // stay inside this frame's rows (weight is 0 there)
-      const float* vrow = vb + (row0 + key) * ldv;
+      const T* vrow = vb + (row0 + key) * ldv;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], vrow[j * 32], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], (float)vrow[j * 32], acc[j], 0, 0, 0);
     }
   }
   const float gam = gamma[0];
@@ -128,24 +129,30 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(
     for (int r = 0; r < 16; ++r) {
       const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
       if (qi < NP)
-        out[(row0 + qi) * ld_out + c] = gam * acc[j][r] + res[(row0 + qi) * ld_res + c];
+        out[(row0 + qi) * ld_out + c] = (T)(gam * acc[j][r] + (float)res[(row0 + qi) * ld_res + c]);
     }
   }
 }
 
 }  // namespace
 
-int launch_cross_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                           const float* res, int ld_res, const float* gamma_dev, float* out,
-                           int ld_out, int batch, hipStream_t stream) {
+int launch_cross_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
+                           const void* res, int ld_res, const float* gamma_dev, void* out,
+                           int ld_out, int batch, hipStream_t stream, int dtype) {
   CASYNC_REQUIRE(q && k && v && res && gamma_dev && out, "cross_attention: null pointer");
   CASYNC_REQUIRE(batch > 0, "cross_attention: batch %d", batch);
   CASYNC_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldq >= DQK && ldk >= DQK && ldv >= CV &&
                      ld_res >= CV && ld_out >= CV,
                  "cross_attention: bad leading dimensions");
   CASYNC_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0, "cross_attention: Q/K alignment");
-  hipLaunchKernelGGL(cross_attention_kernel, dim3(batch, 4), dim3(256), 0, stream, q, ldq, k, ldk, v,
-                     ldv, res, ld_res, gamma_dev, out, ld_out);
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(cross_attention_kernel<bf16_t>, dim3(batch, 4), dim3(256), 0, stream, (const bf16_t*)q, ldq,
+                       (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)res, ld_res, gamma_dev,
+                       (bf16_t*)out, ld_out);
+  else
+    hipLaunchKernelGGL(cross_attention_kernel<float>, dim3(batch, 4), dim3(256), 0, stream, (const float*)q, ldq,
+                       (const float*)k, ldk, (const float*)v, ldv, (const float*)res, ld_res, gamma_dev,
+                       (float*)out, ld_out);
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }

@@ -10,6 +10,28 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Activation storage type of an engine / operator call.  Arithmetic is always fp32
+// (accumulate, bias, activation, softmax); DT_BF16 stores activations and feeds the matrix
+// cores as bf16 (BASELINE configs[2]).
+enum DType { DT_F32 = 0, DT_BF16 = 1 };
+inline int dtype_size(int dt) { return dt == DT_BF16 ? 2 : 4; }
+
+// 4 consecutive activation elements <-> float4 (the unit every HBM-bound kernel moves per lane)
+template <typename T> __device__ __forceinline__ f32x4 ld4(const T* p);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 ld4<bf16_t>(const bf16_t* p) {
+  const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, f32x4 v) {
+  *reinterpret_cast<bf16x4*>(p) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+}
 
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : v * CASYNC_LRELU_SLOPE; }
 
@@ -34,52 +56,55 @@ void casync_set_error(const char* fmt, ...);
   } while (0)
 
 // ---- GEMM (1x1 conv / linear) -------------------------------------------
+// Pointers marked (T) have the activation storage type of the call; the rest are fp32.
 struct GemmEpilogue {
   const float* bias = nullptr;       // [N]
-  const float* pre_res = nullptr;    // [M, ld_pre]  added before the activation ...
+  const void* pre_res = nullptr;     // (T) [M, ld_pre]  added before the activation ...
   const float* pre_scale = nullptr;  // [N]          ... scaled per column (null = 1)
   int ld_pre = 0;
   int act = 0;                       // LeakyReLU(0.01)
-  const float* post_res = nullptr;   // [M, ld_post] added after the activation
+  const void* post_res = nullptr;    // (T) [M, ld_post] added after the activation
   int ld_post = 0;
   const float* aff_s = nullptr;      // [N] v = lrelu(v*aff_s + aff_t) on the OUTPUT (aff_on_acc=0)
   const float* aff_t = nullptr;      //     or on the running accumulator (aff_on_acc=1)
   int aff_on_acc = 0;
-  const float* acc_in = nullptr;     // running sum: acc_out = acc_in + v
-  float* acc_out = nullptr;
+  const void* acc_in = nullptr;      // (T) running sum: acc_out = acc_in + v
+  void* acc_out = nullptr;           // (T)
   int ld_acc = 0;
 };
 
-const char* pw_gemm_kernel_name(int m, int n);
-int launch_pw_gemm(const float* a, int lda, const float* w, float* c, int ldc, int m, int n, int k,
-                   const GemmEpilogue& epi, hipStream_t stream);
+const char* pw_gemm_kernel_name(int m, int n, int dtype = DT_F32);
+// a, w, c (and the (T) epilogue pointers) are `dtype` elements; lda/ldc in elements
+int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int m, int n, int k,
+                   const GemmEpilogue& epi, hipStream_t stream, int dtype = DT_F32);
 
 // ---- other operators -------------------------------------------------------
-int launch_dw3x3(const float* in, const float* w, const float* bias, float* out, int batch, int h,
-                 int wdt, int c, int stride, hipStream_t stream);
+int launch_dw3x3(const void* in, const float* w, const float* bias, void* out, int batch, int h,
+                 int wdt, int c, int stride, hipStream_t stream, int dtype = DT_F32);
 bool ir_fused_supported(int cin, int cout, int stride);
 const char* ir_fused_kernel_name(int cin, int cout, int stride);
 bool ir_fused_up_supported(int cin, int cout);
-int launch_ir_fused_up(const float* lo, int ld_lo, int c_lo, const float* in, int ld_in, const float* w1,
+int launch_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const float* w1,
                        const float* b1, const float* wd, const float* bd, const float* w2,
-                       const float* b2, float* out, int ld_out, int batch, int h, int w, int cin,
-                       int cout, hipStream_t stream);
-int launch_ir_fused(const float* in, int ld_in, const float* w1, const float* b1, const float* wd,
-                    const float* bd, const float* w2, const float* b2, float* out, int ld_out,
+                       const float* b2, void* out, int ld_out, int batch, int h, int w, int cin,
+                       int cout, hipStream_t stream, int dtype = DT_F32);
+int launch_ir_fused(const void* in, int ld_in, const float* w1, const float* b1, const float* wd,
+                    const float* bd, const float* w2, const float* b2, void* out, int ld_out,
                     int batch, int h, int w, int cin, int cout, int stride, int res,
-                    hipStream_t stream);
-int launch_im2col3x3(const float* in, float* out, int batch, int h, int wdt, int c, int stride,
-                     int pad, hipStream_t stream);
-int launch_upsample2x(const float* in, float* out, int ldc, int batch, int h, int wdt, int c,
-                      hipStream_t stream);
-int launch_cross_attention(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                           const float* res, int ld_res, const float* gamma_dev, float* out,
-                           int ld_out, int batch, hipStream_t stream);
-int launch_nchw_to_nhwc(const float* in, float* out, int batch, int c, int hw, hipStream_t stream);
-int launch_inc(const float* x_nchw, const float* packed_inc, float* out, int ldc, int batch,
-               hipStream_t stream);
-int launch_outc(const float* in, int ld_in, const float* w, const float* b, float* out_nchw,
-                int batch, hipStream_t stream);
+                    hipStream_t stream, int dtype = DT_F32);
+int launch_im2col3x3(const void* in, void* out, int batch, int h, int wdt, int c, int stride,
+                     int pad, hipStream_t stream, int dtype = DT_F32);
+int launch_upsample2x(const void* in, void* out, int ldc, int batch, int h, int wdt, int c,
+                      hipStream_t stream, int dtype = DT_F32);
+int launch_cross_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
+                           const void* res, int ld_res, const float* gamma_dev, void* out,
+                           int ld_out, int batch, hipStream_t stream, int dtype = DT_F32);
+int launch_nchw_to_nhwc(const float* in, void* out, int batch, int c, int hw, hipStream_t stream,
+                        int dtype = DT_F32);
+int launch_inc(const float* x_nchw, const float* packed_inc, void* out, int ldc, int batch,
+               hipStream_t stream, int dtype = DT_F32);
+int launch_outc(const void* in, int ld_in, const float* w, const float* b, float* out_nchw,
+                int batch, hipStream_t stream, int dtype = DT_F32);
 
 // packed sub-offsets of the `inc` block inside its packed tensors (floats)
 constexpr int INC_CIN = 6, INC_CEXP = 12, INC_COUT = 32;

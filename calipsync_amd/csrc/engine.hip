@@ -131,13 +131,24 @@ const Layout& layout() {
 }
 
 // ------------------------------------------------------------------ workspace arena
+// An activation pointer that knows its element size: `p + n` advances n ELEMENTS of the engine's
+// storage type (fp32 or bf16) and it converts to void* at the kernel launchers.
+struct Ptr {
+  char* p = nullptr;
+  int esz = 4;
+  Ptr operator+(long long n) const { return Ptr{p + n * esz, esz}; }
+  operator void*() const { return p; }
+  operator const void*() const { return p; }
+};
+
 struct Arena {
   // per-frame float counts; pointers are filled by bind()
   struct Buf {
     const char* name;
     int64_t per_frame;
-    float* p;
+    char* p;
   };
+  int esz = 4;
   enum Id {
     CAT4, CAT3, CAT2, CAT1, CATA, E1, E2, T0, U4, F, FM, U1, U2, U3,
     A0, AC1, AC2, IM, AC3, AC4, AC5, AC6, AE1, AE2,
@@ -156,32 +167,35 @@ struct Arena {
       {"OX1", 100 * 1024, 0},       {"OX2", 100 * 1024, 0},      {"OX3", 100 * 1024, 0},
       {"KX", 100 * 1024, 0},        {"KXF", 100 * 1024, 0},      {"P1", 100 * 512, 0},
       {"AO", 100 * 512, 0},         {"Q", 100 * 64, 0},          {"KV", 100 * kBlocks * kKV, 0}};
-  static int64_t bytes(int batch) {
+  static int64_t bytes(int batch, int esz = 4) {
     Arena a;
     int64_t tot = 0;
     for (auto& x : a.b) tot += (x.per_frame * batch + 63) / 64 * 64;
-    return tot * (int64_t)sizeof(float);
+    return tot * (int64_t)esz;
   }
-  void bind(void* base, int batch) {
-    float* p = (float*)base;
+  void bind(void* base, int batch, int elem_size) {
+    esz = elem_size;
+    char* p = (char*)base;
     for (auto& x : b) {
       x.p = p;
-      p += (x.per_frame * batch + 63) / 64 * 64;
+      p += ((x.per_frame * batch + 63) / 64 * 64) * (int64_t)esz;
     }
   }
   // view of frames [b0, ...) of an arena bound for the whole batch (every buffer is frame-major)
   void slice(int b0) {
-    for (auto& x : b) x.p += x.per_frame * (int64_t)b0;
+    for (auto& x : b) x.p += x.per_frame * (int64_t)b0 * esz;
   }
-  float* operator[](Id i) const { return b[i].p; }
+  Ptr operator[](Id i) const { return Ptr{b[i].p, esz}; }
 };
 
 }  // namespace
 
 struct casync_engine {
   int device = 0;
-  const float* w = nullptr;  // packed weights on the device
+  int dtype = DT_F32;        // activation storage type (DT_BF16: bf16 activations + bf16 GEMM weights)
+  const float* w = nullptr;  // packed weights on the device (fp32: biases, scales, DW / fused-IR weights)
   float* owned = nullptr;
+  bf16_t* w16 = nullptr;     // bf16 image of the whole packed buffer (same element offsets), DT_BF16 only
   // second stream per lane for the audio encoder, which is independent of the face encoder until
   // the fusion MLP (module/unet.py:315-321): forked/joined with events inside casync_forward
   // Lanes: the batch is cut into kMaxLanes contiguous sub-batches that run concurrently, lane 0
@@ -195,9 +209,19 @@ struct casync_engine {
   hipEvent_t ev_start = nullptr;
   bool streams_ready = false;
   const float* W(const std::string& name) const { return w + layout().off(name); }
+  // GEMM weight matrix in the engine's storage type
+  const void* WG(const std::string& name) const {
+    return dtype == DT_BF16 ? (const void*)(w16 + layout().off(name)) : (const void*)(w + layout().off(name));
+  }
 };
 
 namespace {
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ in,
+                                                          bf16_t* __restrict__ out, long long n) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i < n) st4(out + i, ld4(in + i));
+}
 
 // ------------------------------------------------------------------ launch recorder
 struct Runner {
@@ -258,39 +282,48 @@ struct Plan {
   int fuse_min_hw = env_int("CASYNC_FUSE_MIN_HW", 32);   // fuse stages at least this large
 
   // GEMM wrapper with work accounting (algorithmic bytes: A + C once, W once)
-  void gemm(const std::string& tag, const float* a, int lda, const std::string& wname, float* c,
+  int dt() const { return e.dtype; }
+  const char* tn() const { return e.dtype == DT_BF16 ? "__bf16" : "float"; }
+  std::string kname(const char* base, const char* rest = "") const {
+    return std::string(base) + "<" + tn() + rest + ">";
+  }
+
+  void gemm(const std::string& tag, const void* a, int lda, const std::string& wname, void* c,
             int ldc, long long m, int n, int k, GemmEpilogue epi, const std::string& bname = "") {
-    const float* w = e.W(wname);
+    const void* w = e.WG(wname);
     epi.bias = e.W(bname.empty() ? wname.substr(0, wname.size() - 1) + "b" : bname);
-    double bytes = 4.0 * ((double)m * k + (double)m * n + (double)n * k);
-    if (epi.pre_res) bytes += 4.0 * m * n;
-    if (epi.post_res) bytes += 4.0 * m * n;
-    if (epi.acc_out) bytes += 8.0 * m * n;
-    r.run(tag.c_str(), pw_gemm_kernel_name((int)m, n), 2.0 * m * n * k, bytes,
-          [&] { return launch_pw_gemm(a, lda, w, c, ldc, (int)m, n, k, epi, r.s); });
+    const double es = dtype_size(dt());
+    double bytes = es * ((double)m * k + (double)m * n + (double)n * k);
+    if (epi.pre_res) bytes += es * m * n;
+    if (epi.post_res) bytes += es * m * n;
+    if (epi.acc_out) bytes += 2 * es * m * n;
+    r.run(tag.c_str(), pw_gemm_kernel_name((int)m, n, dt()), 2.0 * m * n * k, bytes,
+          [&] { return launch_pw_gemm(a, lda, w, c, ldc, (int)m, n, k, epi, r.s, dt()); });
   }
 
   // One inverted-residual block.  in: [B*hw_in^2, cin] (ld_in); out: [B*hw_out^2, cout] (ld_out).
-  void ir(const IR& b, const float* in, int ld_in, float* out, int ld_out, float* e1, float* e2,
+  void ir(const IR& b, Ptr in, int ld_in, Ptr out, int ld_out, Ptr e1, Ptr e2,
           const GemmEpilogue* extra = nullptr) {
     const std::string p = b.prefix;
     const long long m_in = (long long)B * b.hw_in * b.hw_in, m_out = (long long)B * b.hw_out() * b.hw_out();
     if (fuse_ir && !extra && b.hw_in >= fuse_min_hw && ir_fused_supported(b.cin, b.cout, b.stride)) {
       const double flops = 2.0 * (m_in * (double)b.cin * b.cexp() + 9.0 * m_out * b.cexp() +
                                   (double)m_out * b.cexp() * b.cout);
-      r.run((p + ".fused").c_str(), ir_fused_kernel_name(b.cin, b.cout, b.stride), flops, 4.0 * (m_in * (double)b.cin + (double)m_out * b.cout), [&] {
+      r.run((p + ".fused").c_str(), ir_fused_kernel_name(b.cin, b.cout, b.stride), flops,
+            dtype_size(dt()) * (m_in * (double)b.cin + (double)m_out * b.cout), [&] {
         return launch_ir_fused(in, ld_in, e.W(p + ".pw1.w"), e.W(p + ".pw1.b"), e.W(p + ".dw.w"),
                                e.W(p + ".dw.b"), e.W(p + ".pw2.w"), e.W(p + ".pw2.b"), out, ld_out, B,
-                               b.hw_in, b.hw_in, b.cin, b.cout, b.stride, b.res, r.s);
+                               b.hw_in, b.hw_in, b.cin, b.cout, b.stride, b.res, r.s, dt());
       });
       return;
     }
     GemmEpilogue ep1;
     ep1.act = 1;
     gemm(p + ".pw1", in, ld_in, p + ".pw1.w", e1, b.cexp(), m_in, b.cexp(), b.cin, ep1);
-    r.run((p + ".dw").c_str(), b.stride == 1 ? "dw3x3_kernel<1, 4>" : "dw3x3_kernel<2, 2>", 2.0 * 9 * m_out * b.cexp(), 4.0 * (m_in + m_out) * b.cexp(), [&] {
+    r.run((p + ".dw").c_str(), kname("dw3x3_kernel", b.stride == 1 ? ", 1, 4" : ", 2, 2").c_str(),
+          2.0 * 9 * m_out * b.cexp(), dtype_size(dt()) * (double)(m_in + m_out) * b.cexp(), [&] {
       return launch_dw3x3(e1, e.W(p + ".dw.w"), e.W(p + ".dw.b"), e2, B, b.hw_in, b.hw_in, b.cexp(),
-                          b.stride, r.s);
+                          b.stride, r.s, dt());
     });
     GemmEpilogue ep2;
     if (extra) ep2 = *extra;
@@ -304,7 +337,7 @@ struct Plan {
 
   void forward(const float* x, const float* audio, float* out) {
     using A = Arena;
-    float *E1 = ar[A::E1], *E2 = ar[A::E2], *T0 = ar[A::T0];
+    Ptr E1 = ar[A::E1], E2 = ar[A::E2], T0 = ar[A::T0];
     // The audio encoder and the face encoder are independent until the fusion MLP; with a
     // second stream they run concurrently and the many small 10x10 / 16x16 audio launches fill
     // CUs the face encoder leaves idle.  Profiling mode keeps everything on one stream.
@@ -319,13 +352,13 @@ struct Plan {
       r.s = aux;
     }
     // ---------------- audio encoder (module/unet.py:177-194)
-    float *AE1 = ar[A::AE1], *AE2 = ar[A::AE2];
-    r.run("audio.nchw_to_nhwc", "nchw_to_nhwc_kernel", 0, 8.0 * B * 32768,
-          [&] { return launch_nchw_to_nhwc(audio, ar[A::A0], B, 32, 1024, r.s); });
+    Ptr AE1 = ar[A::AE1], AE2 = ar[A::AE2];
+    r.run("audio.nchw_to_nhwc", kname("nchw_to_nhwc_kernel").c_str(), 0, (4.0 + dtype_size(dt())) * B * 32768,
+          [&] { return launch_nchw_to_nhwc(audio, ar[A::A0], B, 32, 1024, r.s, dt()); });
     ir(kAudio[0], ar[A::A0], 32, ar[A::AC1], 64, AE1, AE2);
     ir(kAudio[1], ar[A::AC1], 64, ar[A::AC2], 128, AE1, AE2);
-    r.run("audio.conv3.im2col", "im2col3x3_kernel", 0, 4.0 * B * (131072 + 256 * 1152), [&] {
-      return launch_im2col3x3(ar[A::AC2], ar[A::IM], B, 32, 32, 128, 2, 1, r.s);
+    r.run("audio.conv3.im2col", kname("im2col3x3_kernel").c_str(), 0, dtype_size(dt()) * (double)B * (131072 + 256 * 1152), [&] {
+      return launch_im2col3x3(ar[A::AC2], ar[A::IM], B, 32, 32, 128, 2, 1, r.s, dt());
     });
     {
       GemmEpilogue ep;
@@ -333,8 +366,8 @@ struct Plan {
       gemm("audio.conv3", ar[A::IM], 1152, "audio_model.conv3.w", ar[A::AC3], 256, (long long)B * 256, 256, 1152, ep);
     }
     ir(kAudio[2], ar[A::AC3], 256, ar[A::AC4], 256, AE1, AE2);
-    r.run("audio.conv5.im2col", "im2col3x3_kernel", 0, 4.0 * B * (65536 + 100 * 2304), [&] {
-      return launch_im2col3x3(ar[A::AC4], ar[A::IM], B, 16, 16, 256, 2, 3, r.s);
+    r.run("audio.conv5.im2col", kname("im2col3x3_kernel").c_str(), 0, dtype_size(dt()) * (double)B * (65536 + 100 * 2304), [&] {
+      return launch_im2col3x3(ar[A::AC4], ar[A::IM], B, 16, 16, 256, 2, 3, r.s, dt());
     });
     {
       GemmEpilogue ep;
@@ -353,10 +386,11 @@ struct Plan {
       r.s = main_s;
     }
     // ---------------- face encoder (module/unet.py:315-319)
-    r.run("inc", "inc_kernel", 2.0 * B * 25600 * (72 + 108 + 384), 4.0 * B * 25600 * (6 + 32), [&] {
-      return launch_inc(x, e.W("inc.inconv.0.fused"), ar[A::CAT4] + 32, 64, B, r.s);
+    r.run("inc", kname("inc_kernel").c_str(), 2.0 * B * 25600 * (72 + 108 + 384),
+          (double)B * 25600 * (6 * 4 + 32 * dtype_size(dt())), [&] {
+      return launch_inc(x, e.W("inc.inconv.0.fused"), ar[A::CAT4] + 32, 64, B, r.s, dt());
     });
-    struct Skip { float* p; int ld; };
+    struct Skip { Ptr p; int ld; };
     const Skip sk[5] = {{ar[A::CAT4] + 32, 64},   {ar[A::CAT3] + 64, 128}, {ar[A::CAT2] + 128, 256},
                         {ar[A::CAT1] + 256, 512}, {ar[A::CATA], 1024}};
     for (int i = 0; i < 4; ++i) {
@@ -369,7 +403,7 @@ struct Plan {
     }
     // ---------------- fusion (module/unet.py:323-326): tx = bn_tx(cat + mlp(cat))
     const long long M10 = (long long)B * 100;
-    float* CATA = ar[A::CATA];
+    Ptr CATA = ar[A::CATA];
     {
       GemmEpilogue ep;
       ep.act = 1;
@@ -383,24 +417,25 @@ struct Plan {
     // K and V projections of the audio features for all four blocks in one GEMM
     gemm("att.kv", CATA + 512, 1024, "att.kv.w", ar[A::KV], kBlocks * kKV, M10, kBlocks * kKV, 512, GemmEpilogue());
     // ---------------- attention blocks (module/unet.py:331-336)
-    float* ox[4] = {ar[A::OX0], ar[A::OX1], ar[A::OX2], ar[A::OX3]};
-    const float* prev = ar[A::TX];
+    Ptr ox[4] = {ar[A::OX0], ar[A::OX1], ar[A::OX2], ar[A::OX3]};
+    Ptr prev = ar[A::TX];
     for (int i = 0; i < kBlocks; ++i) {
       const std::string p = "attention_blocks." + std::to_string(i);
       gemm(p + ".p1", prev, 1024, p + ".p1.w", ar[A::P1], 512, M10, 512, 1024, GemmEpilogue());
       gemm(p + ".q", ar[A::P1], 512, p + ".q.w", ar[A::Q], 64, M10, 64, 512, GemmEpilogue());
-      const float* kv = ar[A::KV] + i * kKV;
-      r.run((p + ".attn").c_str(), "cross_attention_kernel", 2.0 * M10 * 100 * (64 + 512), 4.0 * M10 * (64 + kKV + 1024), [&] {
+      Ptr kv = ar[A::KV] + i * kKV;
+      r.run((p + ".attn").c_str(), kname("cross_attention_kernel").c_str(), 2.0 * M10 * 100 * (64 + 512),
+            dtype_size(dt()) * (double)M10 * (64 + kKV + 1024), [&] {
         return launch_cross_attention(ar[A::Q], 64, kv, kBlocks * kKV, kv + 64, kBlocks * kKV, ar[A::P1],
-                                      512, e.W(p + ".gamma"), ar[A::AO], 512, B, r.s);
+                                      512, e.W(p + ".gamma"), ar[A::AO], 512, B, r.s, dt());
       });
       GemmEpilogue ep;  // lrelu(bn(b_1(ox) + tx)); kx += ox; last block also lrelu(bn_kx(kx))
       ep.pre_res = ar[A::TX];
       ep.ld_pre = 1024;
       ep.pre_scale = e.W(p + ".b1.rs");
       ep.act = 1;
-      ep.acc_in = i == 0 ? ar[A::TX] : ar[A::KX];
-      ep.acc_out = i == kBlocks - 1 ? ar[A::KXF] : ar[A::KX];
+      ep.acc_in = i == 0 ? (const void*)ar[A::TX] : (const void*)ar[A::KX];
+      ep.acc_out = i == kBlocks - 1 ? (void*)ar[A::KXF] : (void*)ar[A::KX];
       ep.ld_acc = 1024;
       if (i == kBlocks - 1) {
         ep.aff_s = e.W("bn_kx.s");
@@ -416,9 +451,9 @@ struct Plan {
     ir(kFuse[2], ar[A::FM], 512, T0, 256, E1, E2);
     ir(kFuse[3], T0, 256, ar[A::F], 256, E1, E2);
     // ---------------- decoder (module/unet.py:338-341)
-    const float* lo = ar[A::F];
-    float* cat[4] = {ar[A::CAT1], ar[A::CAT2], ar[A::CAT3], ar[A::CAT4]};
-    float* uo[4] = {ar[A::U1], ar[A::U2], ar[A::U3], ar[A::U4]};
+    Ptr lo = ar[A::F];
+    Ptr cat[4] = {ar[A::CAT1], ar[A::CAT2], ar[A::CAT3], ar[A::CAT4]};
+    Ptr uo[4] = {ar[A::U1], ar[A::U2], ar[A::U3], ar[A::U4]};
     int hw = 10, c = 256;
     for (int i = 0; i < 4; ++i) {
       const int cc = 2 * c;  // concat width
@@ -427,15 +462,18 @@ struct Plan {
         // bilinear x2 folded into the fused block's input load: up(x) is never materialised
         const std::string p = b0.prefix;
         const double m = (double)B * 4 * hw * hw;
-        r.run((p + ".upfused").c_str(), "ir_fused_kernel<up>", 2.0 * m * (b0.cin * b0.cexp() + 9.0 * b0.cexp() + b0.cexp() * b0.cout),
-              4.0 * (m / 4 * c + m * c + m * b0.cout), [&] {
+        r.run((p + ".upfused").c_str(), ir_fused_kernel_name(b0.cin, b0.cout, 1),
+              2.0 * m * (b0.cin * b0.cexp() + 9.0 * b0.cexp() + b0.cexp() * b0.cout),
+              dtype_size(dt()) * (m / 4 * c + m * c + m * b0.cout), [&] {
                 return launch_ir_fused_up(lo, c, c, cat[i], cc, e.W(p + ".pw1.w"), e.W(p + ".pw1.b"),
                                           e.W(p + ".dw.w"), e.W(p + ".dw.b"), e.W(p + ".pw2.w"),
-                                          e.W(p + ".pw2.b"), T0, b0.cout, B, 2 * hw, 2 * hw, b0.cin, b0.cout, r.s);
+                                          e.W(p + ".pw2.b"), T0, b0.cout, B, 2 * hw, 2 * hw, b0.cin, b0.cout, r.s,
+                                          dt());
               });
       } else {
-        r.run(("up" + std::to_string(i + 1) + ".bilinear").c_str(), "upsample2x_kernel", 0, 4.0 * B * hw * hw * c * 5, [&] {
-          return launch_upsample2x(lo, cat[i], cc, B, hw, hw, c, r.s);
+        r.run(("up" + std::to_string(i + 1) + ".bilinear").c_str(), kname("upsample2x_kernel").c_str(), 0,
+              dtype_size(dt()) * (double)B * hw * hw * c * 5, [&] {
+          return launch_upsample2x(lo, cat[i], cc, B, hw, hw, c, r.s, dt());
         });
         ir(b0, cat[i], cc, T0, b0.cout, E1, E2);
       }
@@ -445,8 +483,8 @@ struct Plan {
       c = kUp[i][1].cout;
     }
     // ---------------- head (module/unet.py:342-344)
-    r.run("outc", "outc_kernel", 2.0 * B * 25600 * 96, 4.0 * B * 25600 * 35, [&] {
-      return launch_outc(ar[A::U4], 32, e.W("outc.w"), e.W("outc.b"), out, B, r.s);
+    r.run("outc", kname("outc_kernel").c_str(), 2.0 * B * 25600 * 96, (double)B * 25600 * (32 * dtype_size(dt()) + 12), [&] {
+      return launch_outc(ar[A::U4], 32, e.W("outc.w"), e.W("outc.b"), out, B, r.s, dt());
     });
   }
 };
@@ -460,9 +498,9 @@ int check_forward_args(casync_handle h, const float* x, const float* a, float* o
     casync_set_error("forward: weights not loaded");
     return CASYNC_ERR_STATE;
   }
-  if (ws_bytes < Arena::bytes(batch)) {
+  if (ws_bytes < Arena::bytes(batch, dtype_size(h->dtype))) {
     casync_set_error("forward: workspace %lld B < required %lld B", (long long)ws_bytes,
-                     (long long)Arena::bytes(batch));
+                     (long long)Arena::bytes(batch, dtype_size(h->dtype)));
     return CASYNC_ERR_STATE;
   }
   CASYNC_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
@@ -484,10 +522,16 @@ const char* casync_packed_name(int i) {
 int64_t casync_packed_offset(int i) { return (i >= 0 && i < casync_packed_count()) ? layout().items[i].offset : -1; }
 int64_t casync_packed_size(int i) { return (i >= 0 && i < casync_packed_count()) ? layout().items[i].size : -1; }
 int64_t casync_packed_total(void) { return layout().total; }
-int64_t casync_workspace_bytes(int batch) { return batch > 0 ? Arena::bytes(batch) : -1; }
+int64_t casync_workspace_bytes(int batch) { return batch > 0 ? Arena::bytes(batch, 4) : -1; }
+int64_t casync_workspace_bytes_dt(int batch, int dtype) {
+  return batch > 0 && (dtype == DT_F32 || dtype == DT_BF16) ? Arena::bytes(batch, dtype_size(dtype)) : -1;
+}
 
-int casync_create(int device_id, casync_handle* out) {
+int casync_create(int device_id, casync_handle* out) { return casync_create_ex(device_id, DT_F32, out); }
+
+int casync_create_ex(int device_id, int dtype, casync_handle* out) {
   CASYNC_REQUIRE(out, "create: null out");
+  CASYNC_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "create: dtype %d (0 = fp32, 1 = bf16)", dtype);
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
     casync_set_error("create: no HIP device visible");
@@ -502,6 +546,7 @@ int casync_create(int device_id, casync_handle* out) {
   }
   casync_engine* e = new casync_engine();
   e->device = device_id;
+  e->dtype = dtype;
   *out = e;
   return CASYNC_OK;
 }
@@ -522,7 +567,18 @@ void casync_destroy(casync_handle h) {
     (void)hipSetDevice(h->device);
     (void)hipFree(h->owned);
   }
+  if (h->w16) (void)hipFree(h->w16);
   delete h;
+}
+
+static int refresh_bf16_weights(casync_handle h, int64_t n) {
+  if (h->dtype != DT_BF16) return CASYNC_OK;
+  if (!h->w16) CASYNC_CHECK_HIP(hipMalloc((void**)&h->w16, n * sizeof(bf16_t)));
+  const long long blocks = (n / 4 + 255) / 256;   // packed total is a multiple of 64 floats
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, h->w, h->w16, (long long)n);
+  CASYNC_CHECK_HIP(hipGetLastError());
+  CASYNC_CHECK_HIP(hipDeviceSynchronize());   // one-time, at weight load (not on the forward path)
+  return CASYNC_OK;
 }
 
 int casync_load_weights_host(casync_handle h, const float* packed, int64_t n_floats) {
@@ -533,7 +589,7 @@ int casync_load_weights_host(casync_handle h, const float* packed, int64_t n_flo
   if (!h->owned) CASYNC_CHECK_HIP(hipMalloc((void**)&h->owned, n_floats * sizeof(float)));
   CASYNC_CHECK_HIP(hipMemcpy(h->owned, packed, n_floats * sizeof(float), hipMemcpyHostToDevice));
   h->w = h->owned;
-  return CASYNC_OK;
+  return refresh_bf16_weights(h, n_floats);
 }
 
 int casync_load_weights_device(casync_handle h, const float* packed_dev, int64_t n_floats) {
@@ -542,7 +598,7 @@ int casync_load_weights_device(casync_handle h, const float* packed_dev, int64_t
                  (long long)n_floats, (long long)layout().total);
   CASYNC_REQUIRE(((uintptr_t)packed_dev % 256) == 0, "load_weights_device: buffer must be 256-B aligned");
   h->w = packed_dev;
-  return CASYNC_OK;
+  return refresh_bf16_weights(h, n_floats);
 }
 
 static int ensure_streams(casync_handle h) {
@@ -581,7 +637,7 @@ int casync_forward(casync_handle h, const float* x, const float* a, float* out, 
     r.s = l == 0 ? caller : h->lane_s[l];
     if (l) CASYNC_CHECK_HIP(hipStreamWaitEvent(r.s, h->ev_start, 0));
     Plan p{*h, Arena(), r, bl};
-    p.ar.bind(ws, batch);
+    p.ar.bind(ws, batch, dtype_size(h->dtype));
     p.ar.slice(b0);
     if (overlap) {
       p.aux = h->aux[l];
@@ -615,7 +671,7 @@ int casync_profile_forward(casync_handle h, const float* x, const float* a, floa
     r.s = (hipStream_t)stream;
     r.profile = true;
     Plan p{*h, Arena(), r, bl};
-    p.ar.bind(ws, batch);
+    p.ar.bind(ws, batch, dtype_size(h->dtype));
     p.ar.slice(b0);
     p.forward(x + (size_t)b0 * 6 * 160 * 160, a + (size_t)b0 * 32 * 32 * 32, out + (size_t)b0 * 3 * 160 * 160);
     r.finish();
@@ -626,13 +682,13 @@ int casync_profile_forward(casync_handle h, const float* x, const float* a, floa
   return n;
 }
 
-int64_t casync_tap(casync_handle h, const char* name, int batch, void* ws, float* dst, int64_t dst_floats,
+int64_t casync_tap(casync_handle h, const char* name, int batch, void* ws, void* dst, int64_t dst_floats,
                    casync_stream stream) {
   CASYNC_REQUIRE(h && name && ws && dst && batch > 0, "tap: bad args");
   Arena ar;
-  ar.bind(ws, batch);
+  ar.bind(ws, batch, dtype_size(h->dtype));
   using A = Arena;
-  struct T { const char* n; const float* p; int ld, c, rows; };
+  struct T { const char* n; Ptr p; int ld, c, rows; };
   const T taps[] = {
       {"x1", ar[A::CAT4] + 32, 64, 32, 25600},  {"x2", ar[A::CAT3] + 64, 128, 64, 6400},
       {"x3", ar[A::CAT2] + 128, 256, 128, 1600}, {"x4", ar[A::CAT1] + 256, 512, 256, 400},
@@ -650,7 +706,8 @@ int64_t casync_tap(casync_handle h, const char* name, int batch, void* ws, float
     const int64_t per_frame = (int64_t)t.rows * t.c;
     CASYNC_REQUIRE(dst_floats >= per_frame * batch, "tap %s: dst holds %lld floats, need %lld", name,
                    (long long)dst_floats, (long long)(per_frame * batch));
-    CASYNC_CHECK_HIP(hipMemcpy2DAsync(dst, (size_t)t.c * 4, t.p, (size_t)t.ld * 4, (size_t)t.c * 4,
+    const size_t es = dtype_size(h->dtype);   // dst receives elements of the engine's storage type
+    CASYNC_CHECK_HIP(hipMemcpy2DAsync(dst, (size_t)t.c * es, t.p.p, (size_t)t.ld * es, (size_t)t.c * es,
                                       (size_t)t.rows * batch, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return per_frame;
   }
@@ -659,9 +716,16 @@ int64_t casync_tap(casync_handle h, const char* name, int batch, void* ws, float
 }
 
 // ---- single operators ------------------------------------------------------
-int casync_op_pw_gemm(const float* a, int lda, const float* w, const float* bias, float* c, int ldc,
-                      int m, int n, int k, int act, const float* pre_res, int ld_pre,
-                      const float* pre_scale, const float* post_res, int ld_post, const float* aff_s,
+static thread_local int g_op_dtype = DT_F32;
+int casync_op_set_dtype(int dtype) {
+  CASYNC_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "op_set_dtype: %d", dtype);
+  g_op_dtype = dtype;
+  return CASYNC_OK;
+}
+
+int casync_op_pw_gemm(const void* a, int lda, const void* w, const float* bias, void* c, int ldc,
+                      int m, int n, int k, int act, const void* pre_res, int ld_pre,
+                      const float* pre_scale, const void* post_res, int ld_post, const float* aff_s,
                       const float* aff_t, casync_stream stream) {
   GemmEpilogue e;
   e.bias = bias;
@@ -674,50 +738,50 @@ int casync_op_pw_gemm(const float* a, int lda, const float* w, const float* bias
   e.aff_s = aff_s;
   e.aff_t = aff_t;
   CASYNC_REQUIRE(!aff_s || aff_t, "pw_gemm: aff_s without aff_t");
-  return launch_pw_gemm(a, lda, w, c, ldc, m, n, k, e, (hipStream_t)stream);
+  return launch_pw_gemm(a, lda, w, c, ldc, m, n, k, e, (hipStream_t)stream, g_op_dtype);
 }
-int casync_op_dw3x3(const float* in, const float* w, const float* bias, float* out, int batch, int h,
+int casync_op_dw3x3(const void* in, const float* w, const float* bias, void* out, int batch, int h,
                     int wdt, int c, int stride, casync_stream stream) {
-  return launch_dw3x3(in, w, bias, out, batch, h, wdt, c, stride, (hipStream_t)stream);
+  return launch_dw3x3(in, w, bias, out, batch, h, wdt, c, stride, (hipStream_t)stream, g_op_dtype);
 }
-int casync_op_ir_fused(const float* in, int ld_in, const float* w1, const float* b1, const float* wd,
-                       const float* bd, const float* w2, const float* b2, float* out, int ld_out,
+int casync_op_ir_fused(const void* in, int ld_in, const float* w1, const float* b1, const float* wd,
+                       const float* bd, const float* w2, const float* b2, void* out, int ld_out,
                        int batch, int h, int w, int cin, int cout, int stride, int res,
                        casync_stream stream) {
   return launch_ir_fused(in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out, batch, h, w, cin, cout, stride,
-                         res, (hipStream_t)stream);
+                         res, (hipStream_t)stream, g_op_dtype);
 }
-int casync_op_ir_fused_up(const float* lo, int ld_lo, int c_lo, const float* in, int ld_in, const float* w1,
+int casync_op_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const float* w1,
                           const float* b1, const float* wd, const float* bd, const float* w2,
-                          const float* b2, float* out, int ld_out, int batch, int h, int w, int cin,
+                          const float* b2, void* out, int ld_out, int batch, int h, int w, int cin,
                           int cout, casync_stream stream) {
   return launch_ir_fused_up(lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out, batch, h, w, cin,
-                            cout, (hipStream_t)stream);
+                            cout, (hipStream_t)stream, g_op_dtype);
 }
-int casync_op_im2col3x3(const float* in, float* out, int batch, int h, int wdt, int c, int stride,
+int casync_op_im2col3x3(const void* in, void* out, int batch, int h, int wdt, int c, int stride,
                         int pad, casync_stream stream) {
-  return launch_im2col3x3(in, out, batch, h, wdt, c, stride, pad, (hipStream_t)stream);
+  return launch_im2col3x3(in, out, batch, h, wdt, c, stride, pad, (hipStream_t)stream, g_op_dtype);
 }
-int casync_op_upsample2x(const float* in, float* out, int ldc, int batch, int h, int wdt, int c,
+int casync_op_upsample2x(const void* in, void* out, int ldc, int batch, int h, int wdt, int c,
                          casync_stream stream) {
-  return launch_upsample2x(in, out, ldc, batch, h, wdt, c, (hipStream_t)stream);
+  return launch_upsample2x(in, out, ldc, batch, h, wdt, c, (hipStream_t)stream, g_op_dtype);
 }
-int casync_op_cross_attention(const float* q, int ldq, const float* k, int ldk, const float* v,
-                              int ldv, const float* res, int ld_res, const float* gamma_dev,
-                              float* out, int ld_out, int batch, casync_stream stream) {
+int casync_op_cross_attention(const void* q, int ldq, const void* k, int ldk, const void* v,
+                              int ldv, const void* res, int ld_res, const float* gamma_dev,
+                              void* out, int ld_out, int batch, casync_stream stream) {
   return launch_cross_attention(q, ldq, k, ldk, v, ldv, res, ld_res, gamma_dev, out, ld_out, batch,
-                                (hipStream_t)stream);
+                                (hipStream_t)stream, g_op_dtype);
 }
-int casync_op_nchw_to_nhwc(const float* in, float* out, int batch, int c, int hw, casync_stream stream) {
-  return launch_nchw_to_nhwc(in, out, batch, c, hw, (hipStream_t)stream);
+int casync_op_nchw_to_nhwc(const float* in, void* out, int batch, int c, int hw, casync_stream stream) {
+  return launch_nchw_to_nhwc(in, out, batch, c, hw, (hipStream_t)stream, g_op_dtype);
 }
-int casync_op_inc(const float* x_nchw, const float* packed_inc, float* out, int ldc, int batch,
+int casync_op_inc(const float* x_nchw, const float* packed_inc, void* out, int ldc, int batch,
                   casync_stream stream) {
-  return launch_inc(x_nchw, packed_inc, out, ldc, batch, (hipStream_t)stream);
+  return launch_inc(x_nchw, packed_inc, out, ldc, batch, (hipStream_t)stream, g_op_dtype);
 }
-int casync_op_outc(const float* in, int ld_in, const float* w, const float* b, float* out_nchw,
+int casync_op_outc(const void* in, int ld_in, const float* w, const float* b, float* out_nchw,
                    int batch, casync_stream stream) {
-  return launch_outc(in, ld_in, w, b, out_nchw, batch, (hipStream_t)stream);
+  return launch_outc(in, ld_in, w, b, out_nchw, batch, (hipStream_t)stream, g_op_dtype);
 }
 
 }  // extern "C"

@@ -18,6 +18,11 @@
 // as A and B use the same one.  Row stride 36 floats (144 B) makes those b128 reads
 // bank-conflict free (16 distinct 16-B slots per lane group).
 //
+// The same kernel serves bf16 activations/weights (BASELINE configs[2]): a k-tile is 128 B per
+// row either way (32 floats or 64 bf16), the 16 B a lane reads per operand feed four
+// v_mfma_f32_32x32x2_f32 (fp32) or one v_mfma_f32_32x32x16_bf16 (lane half kh holds k = 8kh..8kh+7
+// of each 16), accumulation is fp32 and the C/D register layout is dtype-independent.
+//
 // Epilogue: accumulators are transposed through LDS (the A/B staging area is dead by then)
 // so that bias / residual / activation run on float4 and every global access is a full
 // coalesced row segment, instead of 4-B-per-lane scatter in the MFMA C layout.
@@ -27,42 +32,59 @@
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;
+constexpr int ROWB = 128;        // bytes of one k-tile row (32 floats / 64 bf16)
+constexpr int LDSB = ROWB + 16;  // padded LDS row stride in bytes (conflict-free b128 reads)
 
 template <int BM, int BN>
 constexpr size_t gemm_lds_bytes() {
-  const size_t stage = 2ull * (BM + BN) * LDS_LD, ctile = (size_t)BM * (BN + 4);
-  return (stage > ctile ? stage : ctile) * sizeof(float);
+  const size_t stage = 2ull * (BM + BN) * LDSB, ctile = (size_t)BM * (BN + 4) * sizeof(float);
+  return stage > ctile ? stage : ctile;
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void pw_gemm_f32_kernel(const float* __restrict__ A, int lda,
-                                                          const float* __restrict__ W,
-                                                          float* __restrict__ C, int ldc, int M,
-                                                          int N, int K, int n_ntiles, int nwg,
-                                                          GemmEpilogue epi) {
+template <typename T> struct MfmaK;   // how one 16-B operand chunk per lane is consumed
+template <> struct MfmaK<float> {
+  static __device__ __forceinline__ f32x16 run(f32x4 a, f32x4 b, f32x16 c) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], c, 0, 0, 0);
+    return c;
+  }
+};
+template <> struct MfmaK<bf16_t> {
+  static __device__ __forceinline__ f32x16 run(f32x4 a, f32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                   c, 0, 0, 0);
+  }
+};
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void pw_gemm_kernel(const T* __restrict__ A, int lda,
+                                                      const T* __restrict__ W, T* __restrict__ C,
+                                                      int ldc, int M, int N, int K, int n_ntiles,
+                                                      int nwg, GemmEpilogue epi) {
+  constexpr int BK = ROWB / (int)sizeof(T);   // k elements per tile
+  constexpr int E16 = 16 / (int)sizeof(T);    // elements per 16-B chunk
   constexpr int NT = 64 * WM * WN;     // threads per workgroup
   constexpr int RPS = NT / 8;          // rows staged per pass (8 lanes per 128-B row chunk)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_PASS = BM / RPS, B_PASS = BN / RPS;
   static_assert(BM % RPS == 0 && BN % RPS == 0, "tile rows must be a multiple of the staging pass");
   constexpr int LDC_S = BN + 4;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                    // [2][BM][LDS_LD]
-  float* Bs = smem + 2 * BM * LDS_LD;  // [2][BN][LDS_LD]
-  float* Cs = smem;                    // [BM][BN+4], epilogue only
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  char* As = smem_raw;                      // [2][BM][LDSB] bytes
+  char* Bs = smem_raw + 2 * BM * LDSB;      // [2][BN][LDSB]
+  float* Cs = reinterpret_cast<float*>(smem_raw);  // [BM][BN+4] fp32, epilogue only
 
   const int tid = threadIdx.x;
-  const int lrow = tid >> 3, lc4 = (tid & 7) * 4;  // staging: 8 lanes cover one 128-B row chunk
+  const int lrow = tid >> 3, lcb = (tid & 7) * 16;   // staging: 8 lanes cover one 128-B row (16 B each)
+  const int lce = (tid & 7) * E16;                     // ... the same column in elements
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave - wm * WN;
   const int r32 = lane & 31, kh = lane >> 5;
   const int nk = K / BK;
 
   f32x4 ra[A_PASS], rb[B_PASS];
-  const float* a_ptr[A_PASS];
-  const float* b_ptr[B_PASS];
+  const T* a_ptr[A_PASS];
+  const T* b_ptr[B_PASS];
 
   // XCD-aware tile order: workgroups b, b+8, ... share an XCD (round-robin dispatch); give each
   // XCD a contiguous run of tiles so the N-tiles of one M-panel hit the same L2.  Bijective
@@ -79,10 +101,10 @@ __global__ __launch_bounds__(64 * WM * WN) void pw_gemm_f32_kernel(const float* 
     for (int p = 0; p < A_PASS; ++p) {
       int row = m0 + lrow + RPS * p;
       row = row < M ? row : M - 1;  // tail rows re-read the last valid row; never stored
-      a_ptr[p] = A + (size_t)row * lda + lc4;
+      a_ptr[p] = A + (size_t)row * lda + lce;
     }
 #pragma unroll
-    for (int p = 0; p < B_PASS; ++p) b_ptr[p] = W + (size_t)(n0 + lrow + RPS * p) * K + lc4;
+    for (int p = 0; p < B_PASS; ++p) b_ptr[p] = W + (size_t)(n0 + lrow + RPS * p) * K + lce;
   };
   auto gload = [&](int kt) {
 #pragma unroll
@@ -93,10 +115,10 @@ __global__ __launch_bounds__(64 * WM * WN) void pw_gemm_f32_kernel(const float* 
   auto sstore = [&](int buf) {
 #pragma unroll
     for (int p = 0; p < A_PASS; ++p)
-      *reinterpret_cast<f32x4*>(As + (buf * BM + lrow + RPS * p) * LDS_LD + lc4) = ra[p];
+      *reinterpret_cast<f32x4*>(As + (buf * BM + lrow + RPS * p) * LDSB + lcb) = ra[p];
 #pragma unroll
     for (int p = 0; p < B_PASS; ++p)
-      *reinterpret_cast<f32x4*>(Bs + (buf * BN + lrow + RPS * p) * LDS_LD + lc4) = rb[p];
+      *reinterpret_cast<f32x4*>(Bs + (buf * BN + lrow + RPS * p) * LDSB + lcb) = rb[p];
   };
 
   // epilogue constants that do not depend on the tile row
@@ -136,24 +158,21 @@ __global__ __launch_bounds__(64 * WM * WN) void pw_gemm_f32_kernel(const float* 
         set_ptrs(m0n, n0n);
         gload(0);       // next tile's first k-tile
       }
-      const float* a_base = As + (buf * BM + wm * (BM / WM) + r32) * LDS_LD + 4 * kh;
-      const float* b_base = Bs + (buf * BN + wn * (BN / WN) + r32) * LDS_LD + 4 * kh;
+      const char* a_base = As + (buf * BM + wm * (BM / WM) + r32) * LDSB + 16 * kh;
+      const char* b_base = Bs + (buf * BN + wn * (BN / WN) + r32) * LDSB + 16 * kh;
 #pragma unroll
-      for (int g = 0; g < BK / 8; ++g) {
+      for (int g = 0; g < 4; ++g) {   // four 32-B column pairs per 128-B row; lane half kh takes one 16-B chunk
         f32x4 fa[TM], fb[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          fa[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * LDS_LD + 8 * g);
+          fa[i] = *reinterpret_cast<const f32x4*>(a_base + i * 32 * LDSB + 32 * g);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          fb[j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * LDS_LD + 8 * g);
+          fb[j] = *reinterpret_cast<const f32x4*>(b_base + j * 32 * LDSB + 32 * g);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) acc[i][j] = MfmaK<T>::run(fa[i], fb[j], acc[i][j]);
       }
       if (kt + 1 < nk) sstore(buf ^ 1);
       __syncthreads();
@@ -181,21 +200,21 @@ __global__ __launch_bounds__(64 * WM * WN) void pw_gemm_f32_kernel(const float* 
       const int row = rr + RPP * p, m = m0 + row;
       if (m >= M) break;
       f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC_S + c4) + bias;
-      if (epi.pre_res) v += pscale * *reinterpret_cast<const f32x4*>(epi.pre_res + (size_t)m * epi.ld_pre + n);
+      if (epi.pre_res) v += pscale * ld4(static_cast<const T*>(epi.pre_res) + (size_t)m * epi.ld_pre + n);
       if (epi.act) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
-      if (epi.post_res) v += *reinterpret_cast<const f32x4*>(epi.post_res + (size_t)m * epi.ld_post + n);
+      if (epi.post_res) v += ld4(static_cast<const T*>(epi.post_res) + (size_t)m * epi.ld_post + n);
       if (epi.aff_s && !epi.aff_on_acc) {
         v = v * as + at;
         v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w);
       }
-      *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n) = v;
+      st4(C + (size_t)m * ldc + n, v);
       if (epi.acc_out) {
-        f32x4 s = *reinterpret_cast<const f32x4*>(epi.acc_in + (size_t)m * epi.ld_acc + n) + v;
+        f32x4 s = ld4(static_cast<const T*>(epi.acc_in) + (size_t)m * epi.ld_acc + n) + v;
         if (epi.aff_s && epi.aff_on_acc) {
           s = s * as + at;
           s.x = lrelu(s.x); s.y = lrelu(s.y); s.z = lrelu(s.z); s.w = lrelu(s.w);
         }
-        *reinterpret_cast<f32x4*>(epi.acc_out + (size_t)m * epi.ld_acc + n) = s;
+        st4(static_cast<T*>(epi.acc_out) + (size_t)m * epi.ld_acc + n, s);
       }
     }
     __syncthreads();  // the C tile aliases the staging buffers the next tile is about to fill
@@ -204,12 +223,12 @@ __global__ __launch_bounds__(64 * WM * WN) void pw_gemm_f32_kernel(const float* 
   }
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_cfg(const float* a, int lda, const float* w, float* c, int ldc, int m, int n, int k,
-               const GemmEpilogue& epi, hipStream_t stream) {
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_cfg_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, int k,
+                 const GemmEpilogue& epi, hipStream_t stream) {
   constexpr size_t lds = gemm_lds_bytes<BM, BN>();
   static bool attr_set = false;
-  auto kern = pw_gemm_f32_kernel<BM, BN, WM, WN>;
+  auto kern = pw_gemm_kernel<T, BM, BN, WM, WN>;
   if (!attr_set) {
     CASYNC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -227,6 +246,16 @@ int launch_cfg(const float* a, int lda, const float* w, float* c, int ldc, int m
                      n_ntiles, (int)nwg, epi);
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, int n, int k,
+               const GemmEpilogue& epi, hipStream_t stream, int dtype) {
+  if (dtype == DT_BF16)
+    return launch_cfg_t<bf16_t, BM, BN, WM, WN>(static_cast<const bf16_t*>(a), lda, static_cast<const bf16_t*>(w),
+                                                static_cast<bf16_t*>(c), ldc, m, n, k, epi, stream);
+  return launch_cfg_t<float, BM, BN, WM, WN>(static_cast<const float*>(a), lda, static_cast<const float*>(w),
+                                             static_cast<float*>(c), ldc, m, n, k, epi, stream);
 }
 
 // Tile choice.  On a 256-CU chip a launch of G workgroups finishes after ceil(G/256) "rounds" of
@@ -256,24 +285,31 @@ int pick_cfg(int m, int n) {
 }  // namespace
 
 // Name of the kernel instance launch_pw_gemm() will pick (as rocprofv3 prints it).
-const char* pw_gemm_kernel_name(int m, int n) {
+const char* pw_gemm_kernel_name(int m, int n, int dtype) {
+  static thread_local char buf[64];
+  const char* t = dtype == DT_BF16 ? "__bf16" : "float";
+  const char* cfg;
   switch (pick_cfg(m, n)) {
-    case C128x128: return "pw_gemm_f32_kernel<128, 128, 2, 2>";
-    case C128x64: return "pw_gemm_f32_kernel<128, 64, 2, 2>";
-    case C64x64: return "pw_gemm_f32_kernel<64, 64, 2, 2>";
-    case C64x32: return "pw_gemm_f32_kernel<64, 32, 2, 1>";
-    case C64x64W2: return "pw_gemm_f32_kernel<64, 64, 2, 1>";
-    default: return "pw_gemm_f32_kernel<128, 32, 4, 1>";
+    case C128x128: cfg = "128, 128, 2, 2"; break;
+    case C128x64: cfg = "128, 64, 2, 2"; break;
+    case C64x64: cfg = "64, 64, 2, 2"; break;
+    case C64x32: cfg = "64, 32, 2, 1"; break;
+    case C64x64W2: cfg = "64, 64, 2, 1"; break;
+    default: cfg = "128, 32, 4, 1"; break;
   }
+  snprintf(buf, sizeof(buf), "pw_gemm_kernel<%s, %s>", t, cfg);
+  return buf;
 }
 
-int launch_pw_gemm(const float* a, int lda, const float* w, float* c, int ldc, int m, int n, int k,
-                   const GemmEpilogue& epi, hipStream_t stream) {
+int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int m, int n, int k,
+                   const GemmEpilogue& epi, hipStream_t stream, int dtype) {
+  const int bk = ROWB / dtype_size(dtype), e16 = 16 / dtype_size(dtype);
   CASYNC_REQUIRE(a && w && c, "pw_gemm: null pointer");
+  CASYNC_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "pw_gemm: dtype %d", dtype);
   CASYNC_REQUIRE(m > 0 && n > 0 && k > 0, "pw_gemm: empty problem m=%d n=%d k=%d", m, n, k);
-  CASYNC_REQUIRE(k % BK == 0, "pw_gemm: K=%d must be a multiple of %d", k, BK);
+  CASYNC_REQUIRE(k % bk == 0, "pw_gemm: K=%d must be a multiple of %d", k, bk);
   CASYNC_REQUIRE(n % 32 == 0, "pw_gemm: N=%d must be a multiple of 32", n);
-  CASYNC_REQUIRE(lda % 4 == 0 && lda >= k, "pw_gemm: lda=%d (K=%d) must be >= K and a multiple of 4", lda, k);
+  CASYNC_REQUIRE(lda % e16 == 0 && lda >= k, "pw_gemm: lda=%d (K=%d) must be >= K and a multiple of %d", lda, k, e16);
   CASYNC_REQUIRE(ldc >= n && ldc % 4 == 0, "pw_gemm: ldc=%d must be >= N=%d and a multiple of 4", ldc, n);
   CASYNC_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)c % 16) == 0,
                  "pw_gemm: A/W/C must be 16-B aligned");
@@ -282,11 +318,11 @@ int launch_pw_gemm(const float* a, int lda, const float* w, float* c, int ldc, i
                      (!epi.acc_out || epi.ld_acc % 4 == 0),
                  "pw_gemm: residual leading dimensions must be multiples of 4");
   switch (pick_cfg(m, n)) {
-    case C128x128: return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream);
-    case C128x64: return launch_cfg<128, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream);
-    case C64x64: return launch_cfg<64, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream);
-    case C64x32: return launch_cfg<64, 32, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream);
-    case C64x64W2: return launch_cfg<64, 64, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream);
-    default: return launch_cfg<128, 32, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream);
+    case C128x128: return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype);
+    case C128x64: return launch_cfg<128, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype);
+    case C64x64: return launch_cfg<64, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype);
+    case C64x32: return launch_cfg<64, 32, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype);
+    case C64x64W2: return launch_cfg<64, 64, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype);
+    default: return launch_cfg<128, 32, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype);
   }
 }

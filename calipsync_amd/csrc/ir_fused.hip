@@ -97,12 +97,12 @@ constexpr int ir_min_waves() {
 // UPS: the first c_lo input channels are not read from `in` but computed on the fly as the
 // bilinear x2 (align_corners=True) upsample of `lo` [B, H/2, W/2, ld_lo] -- the decoder's
 // cat([up(x), skip]) (module/unet.py:90-96) without materialising up(x).
-template <int CIN, int CE, int COUT, int STRIDE, int CC, bool UPS>
+template <typename T, int CIN, int CE, int COUT, int STRIDE, int CC, bool UPS>
 __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void ir_fused_kernel(
-    const float* __restrict__ lo, int ld_lo, int c_lo,
-    const float* __restrict__ in, int ld_in, const float* __restrict__ w1,
+    const T* __restrict__ lo, int ld_lo, int c_lo,
+    const T* __restrict__ in, int ld_in, const float* __restrict__ w1,
     const float* __restrict__ b1, const float* __restrict__ wd, const float* __restrict__ bd,
-    const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ out, int ld_out,
+    const float* __restrict__ w2, const float* __restrict__ b2, T* __restrict__ out, int ld_out,
     int H, int W, int Ho, int Wo, int res) {
   using G = IRGeom<CIN, COUT, STRIDE, CC>;
   constexpr int NCH = CE / CC;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
   const int l15 = lane & 15, q = lane >> 4;
   const int b = blockIdx.z, oy0 = blockIdx.y * G::TH, ox0 = blockIdx.x * TW;
   const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
-  const float* inb = in + (size_t)b * H * W * ld_in;
+  const T* inb = in + (size_t)b * H * W * ld_in;
   // does the halo leave the image?  (workgroup-uniform)
   const bool border = iy0 < 0 || ix0 < 0 || iy0 + G::IH > H || ix0 + G::IW > W;
 
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
     const int hy = hp / G::IW, hx = hp - hy * G::IW;
     const int iy = iy0 + hy, ix = ix0 + hx;
     const bool ok = hp < G::HP && iy >= 0 && iy < H && ix >= 0 && ix < W;
-    const float* src = inb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * ld_in + 4 * q;
+    const T* src = inb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * ld_in + 4 * q;
     if constexpr (UPS) {
       // same arithmetic as upsample2x_kernel / ATen: src = dst*(in-1)/(out-1), l1 = frac, l0 = 1-l1
       const int Hl = H >> 1, Wl = W >> 1;
@@ -190,23 +190,23 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
       const int y0 = (int)fy, x0 = (int)fx;
       const int y1 = y0 + (y0 < Hl - 1), x1 = x0 + (x0 < Wl - 1);
       const float ly1 = fy - y0, lx1 = fx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-      const float* lb = lo + (size_t)b * Hl * Wl * ld_lo + 4 * q;
-      const float* p00 = lb + ((size_t)y0 * Wl + x0) * ld_lo;
-      const float* p01 = lb + ((size_t)y0 * Wl + x1) * ld_lo;
-      const float* p10 = lb + ((size_t)y1 * Wl + x0) * ld_lo;
-      const float* p11 = lb + ((size_t)y1 * Wl + x1) * ld_lo;
+      const T* lb = lo + (size_t)b * Hl * Wl * ld_lo + 4 * q;
+      const T* p00 = lb + ((size_t)y0 * Wl + x0) * ld_lo;
+      const T* p01 = lb + ((size_t)y0 * Wl + x1) * ld_lo;
+      const T* p10 = lb + ((size_t)y1 * Wl + x0) * ld_lo;
+      const T* p11 = lb + ((size_t)y1 * Wl + x1) * ld_lo;
 #pragma unroll
       for (int g = 0; g < G::KG; ++g) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (ok) {
           if (16 * g < c_lo) {
-            const f32x4 v00 = *reinterpret_cast<const f32x4*>(p00 + 16 * g);
-            const f32x4 v01 = *reinterpret_cast<const f32x4*>(p01 + 16 * g);
-            const f32x4 v10 = *reinterpret_cast<const f32x4*>(p10 + 16 * g);
-            const f32x4 v11 = *reinterpret_cast<const f32x4*>(p11 + 16 * g);
+            const f32x4 v00 = ld4(p00 + 16 * g);
+            const f32x4 v01 = ld4(p01 + 16 * g);
+            const f32x4 v10 = ld4(p10 + 16 * g);
+            const f32x4 v11 = ld4(p11 + 16 * g);
             v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
           } else {
-            v = *reinterpret_cast<const f32x4*>(src + 16 * g);
+            v = ld4(src + 16 * g);
           }
         }
         fa[i][g] = v;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
     } else {
 #pragma unroll
       for (int g = 0; g < G::KG; ++g)
-        fa[i][g] = ok ? *reinterpret_cast<const f32x4*>(src + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        fa[i][g] = ok ? ld4(src + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
   wstore(0);
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
   // ---- epilogue: + b2, LReLU -> LDS staging (over E/D/W, 32 columns at a time) -> coalesced
   //      NHWC rows (+ residual) ----
   float* sO = sE;
-  float* outb = out + (size_t)b * Ho * Wo * ld_out;
+  T* outb = out + (size_t)b * Ho * Wo * ld_out;
 #pragma unroll
   for (int n0 = 0; n0 < G::NT3; n0 += 2) {
     if (n0) __syncthreads();  // previous slice fully stored before it is overwritten
@@ -356,20 +356,20 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
         f32x4 v = *reinterpret_cast<const f32x4*>(sO + p * G::LDO + c4);
         const int c = 16 * n0 + c4;
         if (res)  // stride 1, CIN == COUT: the block input pixel (an L2 hit: this tile just read it)
-          v += *reinterpret_cast<const f32x4*>(inb + ((size_t)oy * W + ox) * ld_in + c);
-        *reinterpret_cast<f32x4*>(outb + ((size_t)oy * Wo + ox) * ld_out + c) = v;
+          v += ld4(inb + ((size_t)oy * W + ox) * ld_in + c);
+        st4(outb + ((size_t)oy * Wo + ox) * ld_out + c, v);
       }
     }
   }
 }
 
-template <int CIN, int CE, int COUT, int STRIDE, int CC, bool UPS = false>
-int launch_inst(const float* lo, int ld_lo, int c_lo, const float* in, int ld_in, const float* w1, const float* b1, const float* wd,
-                const float* bd, const float* w2, const float* b2, float* out, int ld_out, int batch,
-                int h, int w, int res, hipStream_t stream) {
+template <typename T, int CIN, int CE, int COUT, int STRIDE, int CC, bool UPS>
+int launch_inst_t(const T* lo, int ld_lo, int c_lo, const T* in, int ld_in, const float* w1, const float* b1,
+                  const float* wd, const float* bd, const float* w2, const float* b2, T* out, int ld_out,
+                  int batch, int h, int w, int res, hipStream_t stream) {
   using G = IRGeom<CIN, COUT, STRIDE, CC>;
   constexpr size_t lds = (size_t)G::total * sizeof(float);
-  auto kern = ir_fused_kernel<CIN, CE, COUT, STRIDE, CC, UPS>;
+  auto kern = ir_fused_kernel<T, CIN, CE, COUT, STRIDE, CC, UPS>;
   static bool attr_set = false;
   if (!attr_set) {
     CASYNC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -382,6 +382,19 @@ int launch_inst(const float* lo, int ld_lo, int c_lo, const float* in, int ld_in
                      b2, out, ld_out, h, w, ho, wo, res);
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
+}
+
+template <int CIN, int CE, int COUT, int STRIDE, int CC, bool UPS = false>
+int launch_inst(int dtype, const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const float* w1,
+                const float* b1, const float* wd, const float* bd, const float* w2, const float* b2,
+                void* out, int ld_out, int batch, int h, int w, int res, hipStream_t stream) {
+  if (dtype == DT_BF16)
+    return launch_inst_t<bf16_t, CIN, CE, COUT, STRIDE, CC, UPS>(
+        (const bf16_t*)lo, ld_lo, c_lo, (const bf16_t*)in, ld_in, w1, b1, wd, bd, w2, b2, (bf16_t*)out, ld_out,
+        batch, h, w, res, stream);
+  return launch_inst_t<float, CIN, CE, COUT, STRIDE, CC, UPS>((const float*)lo, ld_lo, c_lo, (const float*)in,
+                                                              ld_in, w1, b1, wd, bd, w2, b2, (float*)out, ld_out,
+                                                              batch, h, w, res, stream);
 }
 
 }  // namespace
@@ -405,21 +418,21 @@ bool ir_fused_supported(int cin, int cout, int stride) {
 bool ir_fused_up_supported(int cin, int cout) { return cout == 32 && (cin == 64 || cin == 128); }
 
 // Decoder block with the bilinear upsample folded in: logical input = cat([up2x(lo)[c_lo], in[c_lo:cin]]).
-int launch_ir_fused_up(const float* lo, int ld_lo, int c_lo, const float* in, int ld_in, const float* w1,
+int launch_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const float* w1,
                        const float* b1, const float* wd, const float* bd, const float* w2,
-                       const float* b2, float* out, int ld_out, int batch, int h, int w, int cin,
-                       int cout, hipStream_t stream) {
+                       const float* b2, void* out, int ld_out, int batch, int h, int w, int cin,
+                       int cout, hipStream_t stream, int dtype) {
   CASYNC_REQUIRE(lo && in && w1 && b1 && wd && bd && w2 && b2 && out, "ir_fused_up: null pointer");
   CASYNC_REQUIRE(batch > 0 && batch <= 65535 && h > 2 && w > 2 && h % 2 == 0 && w % 2 == 0, "ir_fused_up: bad shape");
   CASYNC_REQUIRE(c_lo > 0 && c_lo < cin && c_lo % 16 == 0 && ld_lo >= c_lo && ld_lo % 4 == 0, "ir_fused_up: bad c_lo/ld_lo");
   CASYNC_REQUIRE(ld_in >= cin && ld_in % 4 == 0 && ld_out >= cout && ld_out % 4 == 0, "ir_fused_up: bad ld");
   CASYNC_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)lo % 16) == 0, "ir_fused_up: alignment");
   if (cin == 64 && cout == 32)
-    return launch_inst<64, 128, 32, 1, 16, true>(lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out,
-                                                 batch, h, w, 0, stream);
+    return launch_inst<64, 128, 32, 1, 16, true>(dtype, lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2, out,
+                                                 ld_out, batch, h, w, 0, stream);
   if (cin == 128 && cout == 32)
-    return launch_inst<128, 256, 32, 1, 16, true>(lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out,
-                                                  batch, h, w, 0, stream);
+    return launch_inst<128, 256, 32, 1, 16, true>(dtype, lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2, out,
+                                                  ld_out, batch, h, w, 0, stream);
   casync_set_error("ir_fused_up: no instance for cin=%d cout=%d", cin, cout);
   return CASYNC_ERR_ARG;
 }
@@ -430,10 +443,10 @@ const char* ir_fused_kernel_name(int cin, int cout, int stride) {
   return buf;
 }
 
-int launch_ir_fused(const float* in, int ld_in, const float* w1, const float* b1, const float* wd,
-                    const float* bd, const float* w2, const float* b2, float* out, int ld_out,
+int launch_ir_fused(const void* in, int ld_in, const float* w1, const float* b1, const float* wd,
+                    const float* bd, const float* w2, const float* b2, void* out, int ld_out,
                     int batch, int h, int w, int cin, int cout, int stride, int res,
-                    hipStream_t stream) {
+                    hipStream_t stream, int dtype) {
   CASYNC_REQUIRE(in && w1 && b1 && wd && bd && w2 && b2 && out, "ir_fused: null pointer");
   CASYNC_REQUIRE(batch > 0 && batch <= 65535 && h > 1 && w > 1, "ir_fused: bad shape");
   CASYNC_REQUIRE(ld_in >= cin && ld_in % 4 == 0 && ld_out >= cout && ld_out % 4 == 0, "ir_fused: bad ld");
@@ -441,8 +454,8 @@ int launch_ir_fused(const float* in, int ld_in, const float* w1, const float* b1
   CASYNC_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0, "ir_fused: alignment");
 #define IR_CASE(CI, CO, S)                                                                          \
   if (cin == CI && cout == CO && stride == S)                                                       \
-    return launch_inst<CI, 2 * CI, CO, S, 16>(nullptr, 0, 0, in, ld_in, w1, b1, wd, bd, w2, b2, out,  \
-                                              ld_out, batch, h, w, res, stream);
+    return launch_inst<CI, 2 * CI, CO, S, 16>(dtype, nullptr, 0, 0, in, ld_in, w1, b1, wd, bd, w2, b2, \
+                                              out, ld_out, batch, h, w, res, stream);
   IR_CASE(32, 32, 1)    // up4.ir1, up3.ir1
   IR_CASE(64, 32, 1)    // up4.ir0
   IR_CASE(128, 32, 1)   // up3.ir0

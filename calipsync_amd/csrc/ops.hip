@@ -16,11 +16,11 @@ namespace {
 // One thread = 4 channels x PX consecutive output pixels of one row; the (PX-1)*S+3 input
 // columns it needs are held in registers and slid over, so each input float4 is loaded once
 // per row of taps instead of 3 times.
-template <int STRIDE, int PX>
-__global__ __launch_bounds__(256) void dw3x3_kernel(const float* __restrict__ in,
+template <typename T, int STRIDE, int PX>
+__global__ __launch_bounds__(256) void dw3x3_kernel(const T* __restrict__ in,
                                                     const float* __restrict__ w,
                                                     const float* __restrict__ bias,
-                                                    float* __restrict__ out, int H, int W, int C,
+                                                    T* __restrict__ out, int H, int W, int C,
                                                     int Ho, int Wo, int strips, long long total) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
@@ -47,33 +47,33 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const float* __restrict__ in
   for (int ky = 0; ky < 3; ++ky) {
     const int iy = iy0 + ky;
     if (iy < 0 || iy >= H) continue;  // zero padding
-    const float* row = in + ((size_t)b * H + iy) * (size_t)W * C + c;
+    const T* row = in + ((size_t)b * H + iy) * (size_t)W * C + c;
     f32x4 v[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const int ix = ix0 + j;
-      v[j] = (ix >= 0 && ix < W) ? *reinterpret_cast<const f32x4*>(row + (size_t)ix * C)
-                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+      v[j] = (ix >= 0 && ix < W) ? ld4(row + (size_t)ix * C) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int p = 0; p < PX; ++p)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) acc[p] += v[p * STRIDE + kx] * wt[ky * 3 + kx];
   }
-  float* orow = out + ((size_t)b * Ho + oy) * (size_t)Wo * C + c;
+  T* orow = out + ((size_t)b * Ho + oy) * (size_t)Wo * C + c;
 #pragma unroll
   for (int p = 0; p < PX; ++p) {
     if (ox0 + p < Wo) {
       f32x4 r = acc[p];
       r.x = lrelu(r.x); r.y = lrelu(r.y); r.z = lrelu(r.z); r.w = lrelu(r.w);
-      *reinterpret_cast<f32x4*>(orow + (size_t)(ox0 + p) * C) = r;
+      st4(orow + (size_t)(ox0 + p) * C, r);
     }
   }
 }
 
 // ---------------------------------------------------------------- im2col (dense 3x3)
-__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ in,
-                                                        float* __restrict__ out, int H, int W,
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ in,
+                                                        T* __restrict__ out, int H, int W,
                                                         int C, int Ho, int Wo, int stride, int pad,
                                                         long long total) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -89,16 +89,16 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict_
   const int b = (int)(t2 / Ho);
   const int iy = oy * stride - pad + tap / 3, ix = ox * stride - pad + tap % 3;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-    v = *reinterpret_cast<const f32x4*>(in + (((size_t)b * H + iy) * W + ix) * C + c);
-  *reinterpret_cast<f32x4*>(out + (size_t)t * 9 * C + (size_t)tap * C + c) = v;
+  if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ld4(in + (((size_t)b * H + iy) * W + ix) * C + c);
+  st4(out + (size_t)t * 9 * C + (size_t)tap * C + c, v);
 }
 
 // ---------------------------------------------------------------- bilinear x2
 // align_corners=True: src = dst * (in-1)/(out-1); weights as ATen computes them
 // (lambda1 = src - floor(src), lambda0 = 1 - lambda1).
-__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ in,
-                                                         float* __restrict__ out, int ldc, int H,
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ in,
+                                                         T* __restrict__ out, int ldc, int H,
                                                          int W, int C, long long total) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
@@ -115,18 +115,19 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
   const int y0 = (int)fy, x0 = (int)fx;
   const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
   const float ly1 = fy - y0, lx1 = fx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-  const float* base = in + (size_t)b * H * W * C + c;
-  const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x0) * C);
-  const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x1) * C);
-  const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x0) * C);
-  const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x1) * C);
+  const T* base = in + (size_t)b * H * W * C + c;
+  const f32x4 v00 = ld4(base + ((size_t)y0 * W + x0) * C);
+  const f32x4 v01 = ld4(base + ((size_t)y0 * W + x1) * C);
+  const f32x4 v10 = ld4(base + ((size_t)y1 * W + x0) * C);
+  const f32x4 v11 = ld4(base + ((size_t)y1 * W + x1) * C);
   const f32x4 r = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
-  *reinterpret_cast<f32x4*>(out + (((size_t)b * Ho + oy) * Wo + ox) * ldc + c) = r;
+  st4(out + (((size_t)b * Ho + oy) * Wo + ox) * ldc + c, r);
 }
 
 // ---------------------------------------------------------------- NCHW -> NHWC
+template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in,
-                                                           float* __restrict__ out, int C, int HW,
+                                                           T* __restrict__ out, int C, int HW,
                                                            long long total) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
   const int b = (int)(t / c4n);
   const float* src = in + ((size_t)b * C + c) * HW + p;
   f32x4 v = {src[0], src[HW], src[2 * (size_t)HW], src[3 * (size_t)HW]};
-  *reinterpret_cast<f32x4*>(out + ((size_t)b * HW + p) * C + c) = v;
+  st4(out + ((size_t)b * HW + p) * C + c, v);
 }
 
 // ---------------------------------------------------------------- inc (6 -> 12 -> dw -> 32)
@@ -149,9 +150,10 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 constexpr int INC_TW = 32, INC_TH = 8, INC_HW = 160;
 constexpr int INC_HALO_W = INC_TW + 2, INC_HALO_H = INC_TH + 2, INC_HALO = INC_HALO_W * INC_HALO_H;
 
+template <typename T>
 __global__ __launch_bounds__(256) void inc_kernel(const float* __restrict__ x,
                                                   const float* __restrict__ packed,
-                                                  float* __restrict__ out, int ldc) {
+                                                  T* __restrict__ out, int ldc) {
   __shared__ float E[INC_CEXP][INC_HALO + 4];
   __shared__ float O[256][INC_COUT + 1];
   __shared__ float Wl[620];
@@ -209,16 +211,17 @@ __global__ __launch_bounds__(256) void inc_kernel(const float* __restrict__ x,
     const int pix = i >> 3, c4 = (i & 7) * 4;
     const int py = pix >> 5, px = pix & 31;
     f32x4 v = {O[pix][c4], O[pix][c4 + 1], O[pix][c4 + 2], O[pix][c4 + 3]};
-    *reinterpret_cast<f32x4*>(out + (((size_t)b * INC_HW + ty0 + py) * INC_HW + tx0 + px) * ldc + c4) = v;
+    st4(out + (((size_t)b * INC_HW + ty0 + py) * INC_HW + tx0 + px) * ldc + c4, v);
   }
 }
 
 // ---------------------------------------------------------------- outc (32 -> 3, sigmoid)
-__global__ __launch_bounds__(256) void outc_kernel(const float* __restrict__ in, int ld_in,
+template <typename T>
+__global__ __launch_bounds__(256) void outc_kernel(const T* __restrict__ in, int ld_in,
                                                    const float* __restrict__ w,
                                                    const float* __restrict__ bias,
                                                    float* __restrict__ out) {
-  __shared__ float T[256][33];
+  __shared__ float Ts[256][33];
   __shared__ float Wl[3 * 32 + 3];
   const int tid = threadIdx.x;
   if (tid < 96) Wl[tid] = w[tid];
@@ -228,8 +231,8 @@ __global__ __launch_bounds__(256) void outc_kernel(const float* __restrict__ in,
   for (int j = 0; j < 8; ++j) {
     const int i = j * 256 + tid;
     const int pix = i >> 3, c4 = (i & 7) * 4;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(in + (pix0 + pix) * ld_in + c4);
-    T[pix][c4] = v.x; T[pix][c4 + 1] = v.y; T[pix][c4 + 2] = v.z; T[pix][c4 + 3] = v.w;
+    const f32x4 v = ld4(in + (pix0 + pix) * ld_in + c4);
+    Ts[pix][c4] = v.x; Ts[pix][c4 + 1] = v.y; Ts[pix][c4 + 2] = v.z; Ts[pix][c4 + 3] = v.w;
   }
   __syncthreads();
   const size_t pix = pix0 + tid;
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256) void outc_kernel(const float* __restrict__ in,
   for (int o = 0; o < 3; ++o) {
     float s = Wl[96 + o];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) s += Wl[o * 32 + c] * T[tid][c];
+    for (int c = 0; c < 32; ++c) s += Wl[o * 32 + c] * Ts[tid][c];
     out[(b * 3 + o) * (size_t)(INC_HW * INC_HW) + p] = 1.f / (1.f + expf(-s));
   }
 }
@@ -247,8 +250,13 @@ inline unsigned blocks_for(long long total) { return (unsigned)((total + 255) / 
 
 }  // namespace
 
-int launch_dw3x3(const float* in, const float* w, const float* bias, float* out, int batch, int h,
-                 int wdt, int c, int stride, hipStream_t stream) {
+#define DT_DISPATCH(dtype, CALL_F32, CALL_BF16) \
+  do {                                        \
+    if ((dtype) == DT_BF16) { CALL_BF16; } else { CALL_F32; } \
+  } while (0)
+
+int launch_dw3x3(const void* in, const float* w, const float* bias, void* out, int batch, int h,
+                 int wdt, int c, int stride, hipStream_t stream, int dtype) {
   CASYNC_REQUIRE(in && w && bias && out, "dw3x3: null pointer");
   CASYNC_REQUIRE(batch > 0 && h > 0 && wdt > 0 && c > 0 && c % 4 == 0, "dw3x3: bad shape");
   CASYNC_REQUIRE(stride == 1 || stride == 2, "dw3x3: stride %d", stride);
@@ -257,68 +265,88 @@ int launch_dw3x3(const float* in, const float* w, const float* bias, float* out,
     constexpr int PX = 4;
     const int strips = (wo + PX - 1) / PX;
     const long long total = (long long)batch * ho * strips * (c / 4);
-    hipLaunchKernelGGL((dw3x3_kernel<1, PX>), dim3(blocks_for(total)), dim3(256), 0, stream, in, w,
-                       bias, out, h, wdt, c, ho, wo, strips, total);
+    DT_DISPATCH(dtype,
+                hipLaunchKernelGGL((dw3x3_kernel<float, 1, PX>), dim3(blocks_for(total)), dim3(256), 0, stream,
+                                   (const float*)in, w, bias, (float*)out, h, wdt, c, ho, wo, strips, total),
+                hipLaunchKernelGGL((dw3x3_kernel<bf16_t, 1, PX>), dim3(blocks_for(total)), dim3(256), 0, stream,
+                                   (const bf16_t*)in, w, bias, (bf16_t*)out, h, wdt, c, ho, wo, strips, total));
   } else {
     constexpr int PX = 2;
     const int strips = (wo + PX - 1) / PX;
     const long long total = (long long)batch * ho * strips * (c / 4);
-    hipLaunchKernelGGL((dw3x3_kernel<2, PX>), dim3(blocks_for(total)), dim3(256), 0, stream, in, w,
-                       bias, out, h, wdt, c, ho, wo, strips, total);
+    DT_DISPATCH(dtype,
+                hipLaunchKernelGGL((dw3x3_kernel<float, 2, PX>), dim3(blocks_for(total)), dim3(256), 0, stream,
+                                   (const float*)in, w, bias, (float*)out, h, wdt, c, ho, wo, strips, total),
+                hipLaunchKernelGGL((dw3x3_kernel<bf16_t, 2, PX>), dim3(blocks_for(total)), dim3(256), 0, stream,
+                                   (const bf16_t*)in, w, bias, (bf16_t*)out, h, wdt, c, ho, wo, strips, total));
   }
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }
 
-int launch_im2col3x3(const float* in, float* out, int batch, int h, int wdt, int c, int stride,
-                     int pad, hipStream_t stream) {
+int launch_im2col3x3(const void* in, void* out, int batch, int h, int wdt, int c, int stride,
+                     int pad, hipStream_t stream, int dtype) {
   CASYNC_REQUIRE(in && out && batch > 0 && c % 4 == 0, "im2col: bad args");
   const int ho = (h + 2 * pad - 3) / stride + 1, wo = (wdt + 2 * pad - 3) / stride + 1;
   const long long total = (long long)batch * ho * wo * 9 * (c / 4);
-  hipLaunchKernelGGL(im2col3x3_kernel, dim3(blocks_for(total)), dim3(256), 0, stream, in, out, h,
-                     wdt, c, ho, wo, stride, pad, total);
+  DT_DISPATCH(dtype,
+              hipLaunchKernelGGL(im2col3x3_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream,
+                                 (const float*)in, (float*)out, h, wdt, c, ho, wo, stride, pad, total),
+              hipLaunchKernelGGL(im2col3x3_kernel<bf16_t>, dim3(blocks_for(total)), dim3(256), 0, stream,
+                                 (const bf16_t*)in, (bf16_t*)out, h, wdt, c, ho, wo, stride, pad, total));
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }
 
-int launch_upsample2x(const float* in, float* out, int ldc, int batch, int h, int wdt, int c,
-                      hipStream_t stream) {
+int launch_upsample2x(const void* in, void* out, int ldc, int batch, int h, int wdt, int c,
+                      hipStream_t stream, int dtype) {
   CASYNC_REQUIRE(in && out && batch > 0 && c % 4 == 0 && ldc >= c && ldc % 4 == 0 && h > 1 && wdt > 1,
                  "upsample2x: bad args");
   const long long total = (long long)batch * 4 * h * wdt * (c / 4);
-  hipLaunchKernelGGL(upsample2x_kernel, dim3(blocks_for(total)), dim3(256), 0, stream, in, out, ldc,
-                     h, wdt, c, total);
+  DT_DISPATCH(dtype,
+              hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream,
+                                 (const float*)in, (float*)out, ldc, h, wdt, c, total),
+              hipLaunchKernelGGL(upsample2x_kernel<bf16_t>, dim3(blocks_for(total)), dim3(256), 0, stream,
+                                 (const bf16_t*)in, (bf16_t*)out, ldc, h, wdt, c, total));
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }
 
-int launch_nchw_to_nhwc(const float* in, float* out, int batch, int c, int hw, hipStream_t stream) {
+int launch_nchw_to_nhwc(const float* in, void* out, int batch, int c, int hw, hipStream_t stream, int dtype) {
   CASYNC_REQUIRE(in && out && batch > 0 && c % 4 == 0 && hw > 0, "nchw_to_nhwc: bad args");
   const long long total = (long long)batch * (c / 4) * hw;
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(blocks_for(total)), dim3(256), 0, stream, in, out, c,
-                     hw, total);
+  DT_DISPATCH(dtype,
+              hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream, in,
+                                 (float*)out, c, hw, total),
+              hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(blocks_for(total)), dim3(256), 0, stream, in,
+                                 (bf16_t*)out, c, hw, total));
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }
 
-int launch_inc(const float* x_nchw, const float* packed_inc, float* out, int ldc, int batch,
-               hipStream_t stream) {
+int launch_inc(const float* x_nchw, const float* packed_inc, void* out, int ldc, int batch,
+               hipStream_t stream, int dtype) {
   CASYNC_REQUIRE(x_nchw && packed_inc && out && batch > 0 && ldc >= INC_COUT && ldc % 4 == 0,
                  "inc: bad args");
   CASYNC_REQUIRE(batch <= 65535, "inc: batch %d > 65535 (grid.z)", batch);
-  hipLaunchKernelGGL(inc_kernel, dim3(INC_HW / INC_TW, INC_HW / INC_TH, batch), dim3(256), 0, stream,
-                     x_nchw, packed_inc, out, ldc);
+  const dim3 grid(INC_HW / INC_TW, INC_HW / INC_TH, batch);
+  DT_DISPATCH(dtype,
+              hipLaunchKernelGGL(inc_kernel<float>, grid, dim3(256), 0, stream, x_nchw, packed_inc, (float*)out, ldc),
+              hipLaunchKernelGGL(inc_kernel<bf16_t>, grid, dim3(256), 0, stream, x_nchw, packed_inc, (bf16_t*)out, ldc));
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }
 
-int launch_outc(const float* in, int ld_in, const float* w, const float* b, float* out_nchw,
-                int batch, hipStream_t stream) {
+int launch_outc(const void* in, int ld_in, const float* w, const float* b, float* out_nchw,
+                int batch, hipStream_t stream, int dtype) {
   CASYNC_REQUIRE(in && w && b && out_nchw && batch > 0 && ld_in >= 32 && ld_in % 4 == 0,
                  "outc: bad args");
   const long long blocks = (long long)batch * INC_HW * INC_HW / 256;
-  hipLaunchKernelGGL(outc_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, ld_in, w, b,
-                     out_nchw);
+  DT_DISPATCH(dtype,
+              hipLaunchKernelGGL(outc_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)in,
+                                 ld_in, w, b, out_nchw),
+              hipLaunchKernelGGL(outc_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, stream,
+                                 (const bf16_t*)in, ld_in, w, b, out_nchw));
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }

@@ -101,3 +101,46 @@ def test_empty_and_bad_inputs(net):
         net(torch.zeros(2, 6, 160, 160).cuda(), torch.zeros(1, 32, 32, 32).cuda())
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 6, 160, 160).cuda().half(), torch.zeros(1, 32, 32, 32).cuda())
+
+
+# ------------------------------------------------------------------ bf16 engine (BASELINE configs[2])
+@pytest.fixture(scope="module")
+def net_bf16(recipe_sd):
+    m = Model(6, "hubert", precision="bf16").to("cuda:0")
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe_sd.items()})
+    return m.eval()
+
+
+def test_bf16_engine_error_is_reported_not_hidden(net_bf16, golden):
+    """bf16 activations cannot meet the 1e-3 bar (the reference's own bf16 autocast is
+    9e-3 max / 1.3e-3 mean off its fp32).  Pin the error level so regressions show, and keep
+    it clearly labelled as NOT the parity path."""
+    x, a = recipe.make_inputs(2)
+    out = net_bf16(torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda())
+    assert out.dtype == torch.float32 and out.shape == (2, 3, 160, 160)
+    d = np.abs(out.cpu().numpy() - golden["out.full"])
+    print(f"bf16 engine vs reference golden: max {d.max():.3e} mean {d.mean():.3e}")
+    assert d.max() < 4e-2 and d.mean() < 4e-3
+    assert d.max() > 1e-4          # it really is the bf16 path
+
+
+@pytest.mark.parametrize("name", ["x1", "x5", "a", "tx", "kx", "fuse", "u4"])
+def test_bf16_intermediates_track_fp32(net_bf16, golden, name):
+    x, a = recipe.make_inputs(2)
+    net_bf16(torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda())
+    t = net_bf16.tap(name, 2).cpu().numpy()
+    if f"{name}.full" in golden:
+        ref, got = golden[f"{name}.full"].reshape(-1), t.reshape(-1)
+    else:
+        ref, got = golden[f"{name}.samples"], t.reshape(-1)[sample_indices(t.size)]
+    rel = np.abs(got - ref).max() / max(1.0, float(np.abs(ref).max()))
+    print(f"bf16 {name}: max rel err {rel:.3e}")
+    assert rel < 6e-2
+
+
+def test_bf16_frames_independent(net_bf16):
+    x, a = recipe.make_inputs(5)
+    xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
+    full = net_bf16(xt, at)
+    part = net_bf16(xt[3:4].contiguous(), at[3:4].contiguous())
+    assert torch.equal(full[3:4], part)

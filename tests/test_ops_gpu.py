@@ -254,3 +254,29 @@ def test_ir_fused_with_upsample(lib, recipe_sd, prefix, cin, h):
     ok(lib.casync_op_ir_fused_up(ptr(lod), c_lo, c_lo, ptr(cat), cin, ptr(w1), ptr(b1), ptr(wd), ptr(bd), ptr(w2),
                                  ptr(b2), ptr(out), 32, b, h, h, cin, 32, stream()))
     assert rel_err(nchw(out), ref) < 5e-6
+
+
+# ------------------------------------------------------------------ bf16 storage (BASELINE configs[2])
+@pytest.fixture()
+def bf16_ops(lib):
+    lib.casync_op_set_dtype(1)
+    yield lib
+    lib.casync_op_set_dtype(0)
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (1000, 64, 128), (6400, 1024, 512), (257, 32, 128), (300, 256, 1152)])
+def test_pw_gemm_bf16(bf16_ops, m, n, k):
+    """bf16 operands, fp32 accumulate: exact products of the bf16-rounded inputs, so the only
+    error vs an fp64 reference on the SAME rounded inputs is the final bf16 rounding (2^-9)."""
+    lib = bf16_ops
+    g = torch.Generator().manual_seed(m + n)
+    a = torch.randn(m, k, generator=g).bfloat16()
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).bfloat16()
+    b = torch.randn(n, generator=g)
+    res = torch.randn(m, n, generator=g).bfloat16()
+    ref = F.leaky_relu(a.double() @ w.double().T + b.double(), 0.01) + res.double()
+    ad, wd, bd, rd = a.to(dev()), w.to(dev()), b.to(dev()), res.to(dev())
+    c = torch.empty(m, n, device=dev(), dtype=torch.bfloat16)
+    ok(lib.casync_op_pw_gemm(ptr(ad), k, ptr(wd), ptr(bd), ptr(c), n, m, n, k, 1, 0, 0, 0, ptr(rd), n, 0, 0, stream()))
+    err = (c.cpu().double() - ref).abs() / (ref.abs() + 1.0)
+    assert float(err.max()) < 2 ** -8, float(err.max())

@@ -73,21 +73,26 @@ GEMM_SHAPES = [  # (name, rows per frame, N, K)
 def bench_gemm(args):
     lib = _lib.load()
     s = torch.cuda.current_stream().cuda_stream
+    tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    lib.casync_op_set_dtype(1 if args.dtype == "bf16" else 0)
     for name, rows, n, k in GEMM_SHAPES:
         if args.only and args.only not in name:
             continue
         m = rows * args.batch
-        a = torch.randn(m, k, device=DEV)
-        w = torch.randn(n, k, device=DEV) / k ** 0.5
+        if k % (64 if args.dtype == "bf16" else 32):
+            continue
+        a = torch.randn(m, k, device=DEV).to(tdt)
+        w = (torch.randn(n, k, device=DEV) / k ** 0.5).to(tdt)
         bias = torch.randn(n, device=DEV)
-        c = torch.empty(m, n, device=DEV)
+        c = torch.empty(m, n, device=DEV, dtype=tdt)
 
         def fn():
             st = lib.casync_op_pw_gemm(a.data_ptr(), k, w.data_ptr(), bias.data_ptr(), c.data_ptr(), n, m, n, k, 1,
                                        0, 0, 0, 0, 0, 0, 0, s)
             assert st == 0, lib.casync_last_error()
         ms = time_ms(fn, args.iters)
-        print(f"{name:12s} M={m:7d} N={n:5d} K={k:5d}  {ms:7.3f} ms  {2.0 * m * n * k / ms / 1e9:6.1f} TF", flush=True)
+        gb = (m * k + m * n + n * k) * a.element_size() / ms / 1e6
+        print(f"{name:12s} M={m:7d} N={n:5d} K={k:5d}  {ms:7.3f} ms  {2.0 * m * n * k / ms / 1e9:6.1f} TF  {gb:7.1f} GB/s", flush=True)
 
 
 if __name__ == "__main__":
@@ -96,5 +101,6 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     a = ap.parse_args()
     {"ir": bench_ir, "gemm": bench_gemm}[a.what](a)
