@@ -82,14 +82,15 @@ int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int 
 int launch_dw3x3(const void* in, const float* w, const float* bias, void* out, int batch, int h,
                  int wdt, int c, int stride, hipStream_t stream, int dtype = DT_F32);
 bool ir_fused_supported(int cin, int cout, int stride);
-const char* ir_fused_kernel_name(int cin, int cout, int stride);
+const char* ir_fused_kernel_name(int cin, int cout, int stride, int dtype = DT_F32);
 bool ir_fused_up_supported(int cin, int cout);
-int launch_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const float* w1,
-                       const float* b1, const float* wd, const float* bd, const float* w2,
+int launch_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const void* w1,
+                       const float* b1, const float* wd, const float* bd, const void* w2,
                        const float* b2, void* out, int ld_out, int batch, int h, int w, int cin,
                        int cout, hipStream_t stream, int dtype = DT_F32);
-int launch_ir_fused(const void* in, int ld_in, const float* w1, const float* b1, const float* wd,
-                    const float* bd, const float* w2, const float* b2, void* out, int ld_out,
+// w1 / w2 are in the call's storage type (fp32 or bf16); b1, wd, bd, b2 are always fp32
+int launch_ir_fused(const void* in, int ld_in, const void* w1, const float* b1, const float* wd,
+                    const float* bd, const void* w2, const float* b2, void* out, int ld_out,
                     int batch, int h, int w, int cin, int cout, int stride, int res,
                     hipStream_t stream, int dtype = DT_F32);
 int launch_im2col3x3(const void* in, void* out, int batch, int h, int wdt, int c, int stride,

@@ -309,10 +309,10 @@ struct Plan {
     if (fuse_ir && !extra && b.hw_in >= fuse_min_hw && ir_fused_supported(b.cin, b.cout, b.stride)) {
       const double flops = 2.0 * (m_in * (double)b.cin * b.cexp() + 9.0 * m_out * b.cexp() +
                                   (double)m_out * b.cexp() * b.cout);
-      r.run((p + ".fused").c_str(), ir_fused_kernel_name(b.cin, b.cout, b.stride), flops,
+      r.run((p + ".fused").c_str(), ir_fused_kernel_name(b.cin, b.cout, b.stride, dt()), flops,
             dtype_size(dt()) * (m_in * (double)b.cin + (double)m_out * b.cout), [&] {
-        return launch_ir_fused(in, ld_in, e.W(p + ".pw1.w"), e.W(p + ".pw1.b"), e.W(p + ".dw.w"),
-                               e.W(p + ".dw.b"), e.W(p + ".pw2.w"), e.W(p + ".pw2.b"), out, ld_out, B,
+        return launch_ir_fused(in, ld_in, e.WG(p + ".pw1.w"), e.W(p + ".pw1.b"), e.W(p + ".dw.w"),
+                               e.W(p + ".dw.b"), e.WG(p + ".pw2.w"), e.W(p + ".pw2.b"), out, ld_out, B,
                                b.hw_in, b.hw_in, b.cin, b.cout, b.stride, b.res, r.s, dt());
       });
       return;
@@ -462,11 +462,11 @@ struct Plan {
         // bilinear x2 folded into the fused block's input load: up(x) is never materialised
         const std::string p = b0.prefix;
         const double m = (double)B * 4 * hw * hw;
-        r.run((p + ".upfused").c_str(), ir_fused_kernel_name(b0.cin, b0.cout, 1),
+        r.run((p + ".upfused").c_str(), ir_fused_kernel_name(b0.cin, b0.cout, 1, dt()),
               2.0 * m * (b0.cin * b0.cexp() + 9.0 * b0.cexp() + b0.cexp() * b0.cout),
               dtype_size(dt()) * (m / 4 * c + m * c + m * b0.cout), [&] {
-                return launch_ir_fused_up(lo, c, c, cat[i], cc, e.W(p + ".pw1.w"), e.W(p + ".pw1.b"),
-                                          e.W(p + ".dw.w"), e.W(p + ".dw.b"), e.W(p + ".pw2.w"),
+                return launch_ir_fused_up(lo, c, c, cat[i], cc, e.WG(p + ".pw1.w"), e.W(p + ".pw1.b"),
+                                          e.W(p + ".dw.w"), e.W(p + ".dw.b"), e.WG(p + ".pw2.w"),
                                           e.W(p + ".pw2.b"), T0, b0.cout, B, 2 * hw, 2 * hw, b0.cin, b0.cout, r.s,
                                           dt());
               });
@@ -744,15 +744,15 @@ int casync_op_dw3x3(const void* in, const float* w, const float* bias, void* out
                     int wdt, int c, int stride, casync_stream stream) {
   return launch_dw3x3(in, w, bias, out, batch, h, wdt, c, stride, (hipStream_t)stream, g_op_dtype);
 }
-int casync_op_ir_fused(const void* in, int ld_in, const float* w1, const float* b1, const float* wd,
-                       const float* bd, const float* w2, const float* b2, void* out, int ld_out,
+int casync_op_ir_fused(const void* in, int ld_in, const void* w1, const float* b1, const float* wd,
+                       const float* bd, const void* w2, const float* b2, void* out, int ld_out,
                        int batch, int h, int w, int cin, int cout, int stride, int res,
                        casync_stream stream) {
   return launch_ir_fused(in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out, batch, h, w, cin, cout, stride,
                          res, (hipStream_t)stream, g_op_dtype);
 }
-int casync_op_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const float* w1,
-                          const float* b1, const float* wd, const float* bd, const float* w2,
+int casync_op_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const void* w1,
+                          const float* b1, const float* wd, const float* bd, const void* w2,
                           const float* b2, void* out, int ld_out, int batch, int h, int w, int cin,
                           int cout, casync_stream stream) {
   return launch_ir_fused_up(lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out, batch, h, w, cin,

@@ -363,6 +363,316 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
   }
 }
 
+// =====================================================================================
+// bf16 variant (BASELINE configs[2]): same tiling and phases, but activations, E, D and the two
+// 1x1 weight chunks are bf16 and both GEMMs run on v_mfma_f32_16x16x32_bf16 (fp32 accumulate).
+// A chunk is 32 expanded channels (= the K of one project MFMA).  With the matrix work ~16x
+// cheaper the kernel is bound by the depthwise phase (VALU + LDS) and by HBM, so E/D in bf16
+// halve exactly the traffic that matters.  Operand maps of the 16x16x32 form: lane l supplies
+// A[row l&15][k = 8*(l>>4) + j] and B[k = 8*(l>>4) + j][col l&15], j = 0..7 (one 16-B load).
+// =====================================================================================
+template <int RB>   // swizzled BYTE offset of 16-B column `cb/16` of `row` in an unpadded tile with RB-byte rows
+__device__ __forceinline__ int xsb(int row, int cb) {
+  constexpr int R = RB / 16;
+  constexpr int RPB = R >= 16 ? 1 : 16 / R;
+  constexpr int MASK = (R >= 16 ? 16 : R) - 1;
+  const int key = (row / RPB) & MASK;
+  return row * RB + ((((cb >> 4) ^ key)) << 4) + (cb & 15);
+}
+
+template <int CIN, int COUT, int STRIDE>
+struct IRGeomB {
+  using G = IRGeom<CIN, COUT, STRIDE, 32>;
+  static constexpr int CC = 32;
+  static constexpr int KG = CIN / 32;                         // 32-deep k-groups of the expand GEMM
+  // one weight buffer (bytes): W1c [32][CIN] bf16, W2c [COUT][32] bf16, Wd [9][32] + b1 + bd fp32
+  static constexpr int wW1 = 0, wW2 = wW1 + 32 * CIN * 2, wWd = wW2 + COUT * 64, wB = wWd + 9 * 32 * 4;
+  static constexpr int WBUF = wB + 2 * 32 * 4;
+  static constexpr int oE = 0, oD = oE + G::HP * 64, oW = (oD + G::OP * 64 + 15) / 16 * 16;
+  static constexpr int total = oW + 2 * WBUF;
+  static_assert(G::OP * G::LDO * 4 <= total, "epilogue staging must fit in E+D+W");
+  static_assert(WBUF % 16 == 0, "16-B aligned carve");
+  static constexpr int NW1 = (32 * CIN * 2 / 16 + 255) / 256;   // 16-B pieces per thread
+  static constexpr int NW2 = (COUT * 64 / 16 + 255) / 256;
+  static constexpr int est_regs = 4 * (G::MT1 * KG + G::MT3 * G::NT3 + G::MT1 * 2) + 92;
+  static constexpr int min_waves = est_regs <= 128 ? 4 : (est_regs <= 168 ? 3 : 2);
+};
+
+__device__ __forceinline__ f32x4 mfma16b(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int CIN, int CE, int COUT, int STRIDE, bool UPS>
+__global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void ir_fused_bf16_kernel(
+    const bf16_t* __restrict__ lo, int ld_lo, int c_lo, const bf16_t* __restrict__ in, int ld_in,
+    const bf16_t* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ wd,
+    const float* __restrict__ bd, const bf16_t* __restrict__ w2, const float* __restrict__ b2,
+    bf16_t* __restrict__ out, int ld_out, int H, int W, int Ho, int Wo, int res) {
+  using GB = IRGeomB<CIN, COUT, STRIDE>;
+  using G = typename GB::G;
+  constexpr int CC = 32, NCH = CE / CC;
+  extern __shared__ __attribute__((aligned(16))) char smem_b[];
+  char* sE = smem_b + GB::oE;   // [HP][32] bf16, linear
+  char* sD = smem_b + GB::oD;   // [OP][32] bf16, swizzled
+  char* sW = smem_b + GB::oW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int b = blockIdx.z, oy0 = blockIdx.y * G::TH, ox0 = blockIdx.x * TW;
+  const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
+  const bf16_t* inb = in + (size_t)b * H * W * ld_in;
+  const bool border = iy0 < 0 || ix0 < 0 || iy0 + G::IH > H || ix0 + G::IW > W;
+
+  // ---- weight chunk: global -> registers -> the other half of the LDS weight area ----
+  f32x4 rw1[GB::NW1], rw2[GB::NW2], rwd;
+  auto wload = [&](int ce0) {
+#pragma unroll
+    for (int j = 0; j < GB::NW1; ++j) {
+      const int idx = tid + 256 * j;   // 16-B piece of the contiguous [32][CIN] bf16 chunk
+      if (idx < 4 * CIN) rw1[j] = *reinterpret_cast<const f32x4*>(w1 + (size_t)ce0 * CIN + idx * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < GB::NW2; ++j) {
+      const int idx = tid + 256 * j;   // row = idx/4, 16-B piece idx%4 of the 64-B row slice
+      if (idx < COUT * 4) rw2[j] = *reinterpret_cast<const f32x4*>(w2 + (size_t)(idx >> 2) * CE + ce0 + (idx & 3) * 8);
+    }
+    if (tid < 88) {                    // 11 rows (9 taps, b1, bd) x 32 floats = 88 float4
+      const int t = tid >> 3, c4 = (tid & 7) * 4;
+      const float* src = t < 9 ? wd + (size_t)t * CE : (t == 9 ? b1 : bd);
+      rwd = *reinterpret_cast<const f32x4*>(src + ce0 + c4);
+    }
+  };
+  auto wstore = [&](int buf) {
+    char* wb = sW + buf * GB::WBUF;
+#pragma unroll
+    for (int j = 0; j < GB::NW1; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < 4 * CIN) {
+        const int r = idx / (CIN / 8), cb = (idx - r * (CIN / 8)) * 16;
+        *reinterpret_cast<f32x4*>(wb + GB::wW1 + xsb<CIN * 2>(r, cb)) = rw1[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < GB::NW2; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < COUT * 4) *reinterpret_cast<f32x4*>(wb + GB::wW2 + xsb<64>(idx >> 2, (idx & 3) * 16)) = rw2[j];
+    }
+    if (tid < 88) *reinterpret_cast<f32x4*>(wb + GB::wWd + tid * 16) = rwd;
+  };
+
+  wload(0);
+  // ---- A fragments of this wave's halo rows: HBM -> registers, once ----
+  bf16x8 fa[G::MT1][GB::KG];
+  const bf16x8 zero8 = __builtin_bit_cast(bf16x8, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+  for (int i = 0; i < G::MT1; ++i) {
+    const int hp = 16 * (wave * G::MT1 + i) + l15;
+    const int hy = hp / G::IW, hx = hp - hy * G::IW;
+    const int iy = iy0 + hy, ix = ix0 + hx;
+    const bool ok = hp < G::HP && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const bf16_t* src = inb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * ld_in + 8 * q;
+    if constexpr (UPS) {
+      const int Hl = H >> 1, Wl = W >> 1;
+      const float sy = (float)(Hl - 1) / (float)(H - 1), sx = (float)(Wl - 1) / (float)(W - 1);
+      const float fy = sy * (ok ? iy : 0), fx = sx * (ok ? ix : 0);
+      const int y0 = (int)fy, x0 = (int)fx;
+      const int y1 = y0 + (y0 < Hl - 1), x1 = x0 + (x0 < Wl - 1);
+      const float ly1 = fy - y0, lx1 = fx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+      const bf16_t* lb = lo + (size_t)b * Hl * Wl * ld_lo + 8 * q;
+      const bf16_t* p00 = lb + ((size_t)y0 * Wl + x0) * ld_lo;
+      const bf16_t* p01 = lb + ((size_t)y0 * Wl + x1) * ld_lo;
+      const bf16_t* p10 = lb + ((size_t)y1 * Wl + x0) * ld_lo;
+      const bf16_t* p11 = lb + ((size_t)y1 * Wl + x1) * ld_lo;
+#pragma unroll
+      for (int g = 0; g < GB::KG; ++g) {
+        bf16x8 v = zero8;
+        if (ok) {
+          if (32 * g < c_lo) {
+            const bf16x8 v00 = *reinterpret_cast<const bf16x8*>(p00 + 32 * g);
+            const bf16x8 v01 = *reinterpret_cast<const bf16x8*>(p01 + 32 * g);
+            const bf16x8 v10 = *reinterpret_cast<const bf16x8*>(p10 + 32 * g);
+            const bf16x8 v11 = *reinterpret_cast<const bf16x8*>(p11 + 32 * g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              v[e] = (bf16_t)(ly0 * (lx0 * (float)v00[e] + lx1 * (float)v01[e]) +
+                              ly1 * (lx0 * (float)v10[e] + lx1 * (float)v11[e]));
+          } else {
+            v = *reinterpret_cast<const bf16x8*>(src + 32 * g);
+          }
+        }
+        fa[i][g] = v;
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < GB::KG; ++g) fa[i][g] = ok ? *reinterpret_cast<const bf16x8*>(src + 32 * g) : zero8;
+    }
+  }
+  wstore(0);
+  if (NCH > 1) wload(CC);
+  __syncthreads();
+
+  f32x4 acc3[G::MT3][G::NT3];
+#pragma unroll
+  for (int i = 0; i < G::MT3; ++i)
+#pragma unroll
+    for (int n = 0; n < G::NT3; ++n) acc3[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+  for (int ch = 0; ch < NCH; ++ch) {
+    const char* wb = sW + (ch & 1) * GB::WBUF;
+    const float* wf = reinterpret_cast<const float*>(wb + GB::wWd);   // [9][32] taps, then b1[32], bd[32]
+    // ---- P1: expand GEMM over the halo, bias preloaded into the accumulators ----
+    {
+      f32x4 acc[G::MT1][2];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const float bias = wf[9 * 32 + 16 * n + l15];
+#pragma unroll
+        for (int i = 0; i < G::MT1; ++i) acc[i][n] = f32x4{bias, bias, bias, bias};
+      }
+#pragma unroll
+      for (int g = 0; g < GB::KG; ++g) {
+        bf16x8 fb[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          fb[n] = *reinterpret_cast<const bf16x8*>(wb + GB::wW1 + xsb<CIN * 2>(16 * n + l15, (32 * g + 8 * q) * 2));
+#pragma unroll
+        for (int i = 0; i < G::MT1; ++i)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc[i][n] = mfma16b(fa[i][g], fb[n], acc[i][n]);
+      }
+#pragma unroll
+      for (int i = 0; i < G::MT1; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int hp = 16 * (wave * G::MT1 + i) + 4 * q + r;
+          if (hp < G::HP) {
+            float m = 1.f;
+            if (border) {
+              const int hy = hp / G::IW, hx = hp - hy * G::IW;
+              const int iy = iy0 + hy, ix = ix0 + hx;
+              m = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? 1.f : 0.f;
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+              reinterpret_cast<bf16_t*>(sE)[hp * CC + 16 * n + l15] = (bf16_t)(m * lrelu_max(acc[i][n][r]));
+          }
+        }
+    }
+    __syncthreads();  // E complete; every wave is done with the previous chunk's P3
+    if (ch + 1 < NCH) {
+      wstore((ch + 1) & 1);
+      if (ch + 2 < NCH) wload((ch + 2) * CC);
+    }
+
+    // ---- P2: depthwise 3x3 over E -> D; thread = 8 channels (one 16-B bf16 vector) x NPX pixels ----
+    {
+      constexpr int PPI = 64, NPX = G::OP / PPI;
+      const int c8 = (tid & 3) * 8, p0 = tid >> 2;
+      f32x4 a0[NPX], a1[NPX];
+      const char* e0[NPX];
+#pragma unroll
+      for (int j = 0; j < NPX; ++j) {
+        const int p = p0 + PPI * j, py = p / TW, px = p - py * TW;
+        e0[j] = sE + (((py * STRIDE) * G::IW + px * STRIDE) * CC + c8) * 2;
+        a0[j] = *reinterpret_cast<const f32x4*>(wf + 10 * 32 + c8);
+        a1[j] = *reinterpret_cast<const f32x4*>(wf + 10 * 32 + c8 + 4);
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wf + t * 32 + c8);
+        const f32x4 w1v = *reinterpret_cast<const f32x4*>(wf + t * 32 + c8 + 4);
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) {
+          const bf16x8 e = *reinterpret_cast<const bf16x8*>(e0[j] + ((t / 3) * G::IW + (t % 3)) * CC * 2);
+          a0[j] += f32x4{(float)e[0], (float)e[1], (float)e[2], (float)e[3]} * w0;
+          a1[j] += f32x4{(float)e[4], (float)e[5], (float)e[6], (float)e[7]} * w1v;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NPX; ++j) {
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = (bf16_t)lrelu_max(a0[j][e]);
+          v[e + 4] = (bf16_t)lrelu_max(a1[j][e]);
+        }
+        *reinterpret_cast<bf16x8*>(sD + xsb<64>(p0 + PPI * j, c8 * 2)) = v;
+      }
+    }
+    __syncthreads();  // D complete (and the parked weights are visible)
+
+    // ---- P3: project GEMM, one 32-deep MFMA per output tile and chunk ----
+    {
+      bf16x8 fd[G::MT3], fb[G::NT3];
+#pragma unroll
+      for (int i = 0; i < G::MT3; ++i)
+        fd[i] = *reinterpret_cast<const bf16x8*>(sD + xsb<64>(16 * (wave * G::MT3 + i) + l15, 16 * q));
+#pragma unroll
+      for (int n = 0; n < G::NT3; ++n)
+        fb[n] = *reinterpret_cast<const bf16x8*>(wb + GB::wW2 + xsb<64>(16 * n + l15, 16 * q));
+#pragma unroll
+      for (int i = 0; i < G::MT3; ++i)
+#pragma unroll
+        for (int n = 0; n < G::NT3; ++n) acc3[i][n] = mfma16b(fd[i], fb[n], acc3[i][n]);
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: + b2, LReLU -> fp32 LDS staging (32 columns at a time) -> coalesced bf16 rows ----
+  float* sO = reinterpret_cast<float*>(smem_b);
+  bf16_t* outb = out + (size_t)b * Ho * Wo * ld_out;
+#pragma unroll
+  for (int n0 = 0; n0 < G::NT3; n0 += 2) {
+    if (n0) __syncthreads();
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+      const float bias = b2[16 * (n0 + nn) + l15];
+#pragma unroll
+      for (int i = 0; i < G::MT3; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = 16 * (wave * G::MT3 + i) + 4 * q + r;
+          sO[p * G::LDO + 16 * nn + l15] = lrelu_max(acc3[i][n0 + nn][r] + bias);
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G::OP * 8; idx += 256) {
+      const int p = idx >> 3, c4 = (idx & 7) * 4;
+      const int py = p / TW, px = p - py * TW;
+      const int oy = oy0 + py, ox = ox0 + px;
+      if (oy < Ho && ox < Wo) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(sO + p * G::LDO + c4);
+        const int c = 16 * n0 + c4;
+        if (res) v += ld4(inb + ((size_t)oy * W + ox) * ld_in + c);
+        st4(outb + ((size_t)oy * Wo + ox) * ld_out + c, v);
+      }
+    }
+  }
+}
+
+template <int CIN, int CE, int COUT, int STRIDE, bool UPS>
+int launch_inst_b(const bf16_t* lo, int ld_lo, int c_lo, const bf16_t* in, int ld_in, const bf16_t* w1,
+                  const float* b1, const float* wd, const float* bd, const bf16_t* w2, const float* b2,
+                  bf16_t* out, int ld_out, int batch, int h, int w, int res, hipStream_t stream) {
+  using GB = IRGeomB<CIN, COUT, STRIDE>;
+  using G = typename GB::G;
+  constexpr size_t lds = (size_t)GB::total;
+  auto kern = ir_fused_bf16_kernel<CIN, CE, COUT, STRIDE, UPS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    CASYNC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int ho = (h + 2 - 3) / STRIDE + 1, wo = (w + 2 - 3) / STRIDE + 1;
+  dim3 grid((wo + TW - 1) / TW, (ho + G::TH - 1) / G::TH, batch);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2,
+                     out, ld_out, h, w, ho, wo, res);
+  CASYNC_CHECK_HIP(hipGetLastError());
+  return CASYNC_OK;
+}
+
 template <typename T, int CIN, int CE, int COUT, int STRIDE, int CC, bool UPS>
 int launch_inst_t(const T* lo, int ld_lo, int c_lo, const T* in, int ld_in, const float* w1, const float* b1,
                   const float* wd, const float* bd, const float* w2, const float* b2, T* out, int ld_out,
@@ -384,17 +694,18 @@ int launch_inst_t(const T* lo, int ld_lo, int c_lo, const T* in, int ld_in, cons
   return CASYNC_OK;
 }
 
+// w1 / w2 are in the call's storage type (fp32 or bf16); b1, wd, bd, b2 are always fp32
 template <int CIN, int CE, int COUT, int STRIDE, int CC, bool UPS = false>
-int launch_inst(int dtype, const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const float* w1,
-                const float* b1, const float* wd, const float* bd, const float* w2, const float* b2,
+int launch_inst(int dtype, const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const void* w1,
+                const float* b1, const float* wd, const float* bd, const void* w2, const float* b2,
                 void* out, int ld_out, int batch, int h, int w, int res, hipStream_t stream) {
   if (dtype == DT_BF16)
-    return launch_inst_t<bf16_t, CIN, CE, COUT, STRIDE, CC, UPS>(
-        (const bf16_t*)lo, ld_lo, c_lo, (const bf16_t*)in, ld_in, w1, b1, wd, bd, w2, b2, (bf16_t*)out, ld_out,
-        batch, h, w, res, stream);
+    return launch_inst_b<CIN, CE, COUT, STRIDE, UPS>((const bf16_t*)lo, ld_lo, c_lo, (const bf16_t*)in, ld_in,
+                                                     (const bf16_t*)w1, b1, wd, bd, (const bf16_t*)w2, b2,
+                                                     (bf16_t*)out, ld_out, batch, h, w, res, stream);
   return launch_inst_t<float, CIN, CE, COUT, STRIDE, CC, UPS>((const float*)lo, ld_lo, c_lo, (const float*)in,
-                                                              ld_in, w1, b1, wd, bd, w2, b2, (float*)out, ld_out,
-                                                              batch, h, w, res, stream);
+                                                              ld_in, (const float*)w1, b1, wd, bd, (const float*)w2,
+                                                              b2, (float*)out, ld_out, batch, h, w, res, stream);
 }
 
 }  // namespace
@@ -418,8 +729,8 @@ bool ir_fused_supported(int cin, int cout, int stride) {
 bool ir_fused_up_supported(int cin, int cout) { return cout == 32 && (cin == 64 || cin == 128); }
 
 // Decoder block with the bilinear upsample folded in: logical input = cat([up2x(lo)[c_lo], in[c_lo:cin]]).
-int launch_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const float* w1,
-                       const float* b1, const float* wd, const float* bd, const float* w2,
+int launch_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const void* w1,
+                       const float* b1, const float* wd, const float* bd, const void* w2,
                        const float* b2, void* out, int ld_out, int batch, int h, int w, int cin,
                        int cout, hipStream_t stream, int dtype) {
   CASYNC_REQUIRE(lo && in && w1 && b1 && wd && bd && w2 && b2 && out, "ir_fused_up: null pointer");
@@ -437,14 +748,17 @@ int launch_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, int 
   return CASYNC_ERR_ARG;
 }
 
-const char* ir_fused_kernel_name(int cin, int cout, int stride) {
+const char* ir_fused_kernel_name(int cin, int cout, int stride, int dtype) {
   static thread_local char buf[64];
-  snprintf(buf, sizeof(buf), "ir_fused_kernel<%d, %d, %d, %d, 16>", cin, 2 * cin, cout, stride);
+  if (dtype == DT_BF16)
+    snprintf(buf, sizeof(buf), "ir_fused_bf16_kernel<%d, %d, %d, %d>", cin, 2 * cin, cout, stride);
+  else
+    snprintf(buf, sizeof(buf), "ir_fused_kernel<float, %d, %d, %d, %d, 16>", cin, 2 * cin, cout, stride);
   return buf;
 }
 
-int launch_ir_fused(const void* in, int ld_in, const float* w1, const float* b1, const float* wd,
-                    const float* bd, const float* w2, const float* b2, void* out, int ld_out,
+int launch_ir_fused(const void* in, int ld_in, const void* w1, const float* b1, const float* wd,
+                    const float* bd, const void* w2, const float* b2, void* out, int ld_out,
                     int batch, int h, int w, int cin, int cout, int stride, int res,
                     hipStream_t stream, int dtype) {
   CASYNC_REQUIRE(in && w1 && b1 && wd && bd && w2 && b2 && out, "ir_fused: null pointer");

@@ -127,18 +127,19 @@ int casync_op_dw3x3(const void* in, const float* w, const float* bias, void* out
                     int batch, int h, int wdt, int c, int stride, casync_stream stream);
 /* Whole inverted-residual block in one kernel (expanded tensor stays in LDS); the
  * high-resolution stages use it.  Replaces InvertedResidual.forward
- * (module/unet.py:16-40) with BN folded: w1 [2cin][cin], wd [9][2cin], w2 [cout][2cin].
+ * (module/unet.py:16-40) with BN folded: w1 [2cin][cin], wd [9][2cin], w2 [cout][2cin]
+ * (w1/w2 in the op dtype, the rest fp32).
  * Returns CASYNC_ERR_ARG if (cin, cout, stride) has no instance.              */
-int casync_op_ir_fused(const void* in, int ld_in, const float* w1, const float* b1,
-                       const float* wd, const float* bd, const float* w2, const float* b2,
+int casync_op_ir_fused(const void* in, int ld_in, const void* w1, const float* b1,
+                       const float* wd, const float* bd, const void* w2, const float* b2,
                        void* out, int ld_out, int batch, int h, int w, int cin, int cout,
                        int stride, int res, casync_stream stream);
 /* Decoder variant: the block input is cat([bilinear_x2(lo)[0:c_lo], in[c_lo:cin]]) with the
  * upsample (align_corners=True) computed while loading -- Up.forward's interpolate + cat +
  * first InvertedResidual (module/unet.py:90-97) in one kernel.  lo: [B,h/2,w/2,ld_lo].     */
 int casync_op_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, int ld_in,
-                          const float* w1, const float* b1, const float* wd, const float* bd,
-                          const float* w2, const float* b2, void* out, int ld_out, int batch,
+                          const void* w1, const float* b1, const float* wd, const float* bd,
+                          const void* w2, const float* b2, void* out, int ld_out, int batch,
                           int h, int w, int cin, int cout, casync_stream stream);
 /* im2col for the two dense 3x3 stride-2 convs (module/unet.py:161-168):
  * out[B*Ho*Wo][9*C], column order (ky,kx,c).                                */

@@ -280,3 +280,57 @@ def test_pw_gemm_bf16(bf16_ops, m, n, k):
     ok(lib.casync_op_pw_gemm(ptr(ad), k, ptr(wd), ptr(bd), ptr(c), n, m, n, k, 1, 0, 0, 0, ptr(rd), n, 0, 0, stream()))
     err = (c.cpu().double() - ref).abs() / (ref.abs() + 1.0)
     assert float(err.max()) < 2 ** -8, float(err.max())
+
+
+@pytest.mark.parametrize("prefix,cin,cout,stride,res,h,w", IR_CASES)
+def test_ir_fused_block_bf16(bf16_ops, recipe_sd, prefix, cin, cout, stride, res, h, w):
+    """bf16 fused inverted residual (bf16 MFMA, bf16 E/D tiles) vs the fp32 oracle module on the
+    same bf16-rounded input and weights: the error is the bf16 rounding of E, D and the output."""
+    from oracle import unet_oracle
+    lib = bf16_ops
+    sd = unet_oracle.to_torch(recipe_sd)
+    f = pack.fold(recipe_sd)
+    g = torch.Generator().manual_seed(h * 7 + cin)
+    b = 2
+    x = torch.randn(b, cin, h, w, generator=g).bfloat16().float()
+    ref = unet_oracle.inverted_residual(sd, prefix, x, stride, res)
+    ho, wo = ref.shape[2], ref.shape[3]
+    ld_in, ld_out = cin + 32, cout + 16
+    xin = torch.full((b, h, w, ld_in), 3.0)
+    xin[..., 32:] = x.permute(0, 2, 3, 1)
+    xin = xin.bfloat16().to(dev())
+    out = torch.full((b, ho, wo, ld_out), -5.0, device=dev(), dtype=torch.bfloat16)
+    F32 = lambda k: torch.from_numpy(f[f"{prefix}.{k}"].astype(np.float32)).contiguous().to(dev())
+    B16 = lambda k: F32(k).bfloat16()
+    w1, b1, wd, bd, w2, b2 = B16("pw1.w"), F32("pw1.b"), F32("dw.w"), F32("dw.b"), B16("pw2.w"), F32("pw2.b")
+    ok(lib.casync_op_ir_fused(xin.data_ptr() + 32 * 2, ld_in, ptr(w1), ptr(b1), ptr(wd), ptr(bd), ptr(w2),
+                              ptr(b2), out.data_ptr() + 16 * 2, ld_out, b, h, w, cin, cout, stride,
+                              int(res), stream()))
+    o = out.float().cpu()
+    assert (o[..., :16] == -5).all()
+    got = o[..., 16:].permute(0, 3, 1, 2)
+    err = rel_err(got, ref)
+    assert err < 2e-2, err
+
+
+def test_ir_fused_with_upsample_bf16(bf16_ops, recipe_sd):
+    from oracle import unet_oracle
+    lib = bf16_ops
+    sd = unet_oracle.to_torch(recipe_sd)
+    f = pack.fold(recipe_sd)
+    prefix, cin, h = "up4.conv.double_conv.0", 64, 48
+    g = torch.Generator().manual_seed(9)
+    b, c_lo = 2, cin // 2
+    lo = torch.randn(b, c_lo, h // 2, h // 2, generator=g).bfloat16().float()
+    skip = torch.randn(b, cin - c_lo, h, h, generator=g).bfloat16().float()
+    up = F.interpolate(lo, scale_factor=2, mode="bilinear", align_corners=True)
+    ref = unet_oracle.inverted_residual(sd, prefix, torch.cat([up, skip], 1), 1, False)
+    cat = torch.full((b, h, h, cin), 77.0)
+    cat[..., c_lo:] = skip.permute(0, 2, 3, 1)
+    cat, lod = cat.bfloat16().to(dev()), nhwc(lo).bfloat16()
+    out = torch.empty(b, h, h, 32, device=dev(), dtype=torch.bfloat16)
+    F32 = lambda k: torch.from_numpy(f[f"{prefix}.{k}"].astype(np.float32)).contiguous().to(dev())
+    w1, b1, wd, bd, w2, b2 = F32("pw1.w").bfloat16(), F32("pw1.b"), F32("dw.w"), F32("dw.b"), F32("pw2.w").bfloat16(), F32("pw2.b")
+    ok(lib.casync_op_ir_fused_up(ptr(lod), c_lo, c_lo, ptr(cat), cin, ptr(w1), ptr(b1), ptr(wd), ptr(bd), ptr(w2),
+                                 ptr(b2), ptr(out), 32, b, h, h, cin, 32, stream()))
+    assert rel_err(nchw(out.float()), ref) < 2e-2
