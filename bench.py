@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="frames per GPU per step (default: 64 for f32 = configs[1], 512 for bf16 = configs[2])")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="engine activation storage: f32 = parity path (default), bf16 = BASELINE configs[2]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -92,6 +93,8 @@ def cpu_baseline(sd_np, seconds: float):
 
 def main():
     args = parse()
+    if args.batch <= 0:
+        args.batch = 64 if args.dtype == "f32" else 512
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
