@@ -55,6 +55,34 @@ void casync_set_error(const char* fmt, ...);
     }                                            \
   } while (0)
 
+// 16 bytes of activations (4 floats or 8 bf16) as fp32 lanes: the widest per-lane access
+template <typename T> struct V16 {
+  static constexpr int N = 16 / (int)sizeof(T);
+  float v[N];
+};
+template <typename T> __device__ __forceinline__ V16<T> ld16(const T* p);
+template <> __device__ __forceinline__ V16<float> ld16<float>(const float* p) {
+  const f32x4 x = *reinterpret_cast<const f32x4*>(p);
+  return V16<float>{{x[0], x[1], x[2], x[3]}};
+}
+template <> __device__ __forceinline__ V16<bf16_t> ld16<bf16_t>(const bf16_t* p) {
+  const bf16x8 x = *reinterpret_cast<const bf16x8*>(p);
+  V16<bf16_t> r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = (float)x[i];
+  return r;
+}
+template <typename T> __device__ __forceinline__ void st16(T* p, const V16<T>& r);
+template <> __device__ __forceinline__ void st16<float>(float* p, const V16<float>& r) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{r.v[0], r.v[1], r.v[2], r.v[3]};
+}
+template <> __device__ __forceinline__ void st16<bf16_t>(bf16_t* p, const V16<bf16_t>& r) {
+  bf16x8 x;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = (bf16_t)r.v[i];
+  *reinterpret_cast<bf16x8*>(p) = x;
+}
+
 // ---- GEMM (1x1 conv / linear) -------------------------------------------
 // Pointers marked (T) have the activation storage type of the call; the rest are fp32.
 struct GemmEpilogue {

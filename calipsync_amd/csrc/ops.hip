@@ -22,11 +22,12 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const T* __restrict__ in,
                                                     const float* __restrict__ bias,
                                                     T* __restrict__ out, int H, int W, int C,
                                                     int Ho, int Wo, int strips, long long total) {
+  constexpr int V = V16<T>::N;   // channels per thread = one 16-B access (4 fp32 / 8 bf16)
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
-  const int c4n = C >> 2;
-  const int c = (int)(idx % c4n) * 4;
-  long long t = idx / c4n;
+  const int cvn = C / V;
+  const int c = (int)(idx % cvn) * V;
+  long long t = idx / cvn;
   const int sx = (int)(t % strips);
   t /= strips;
   const int oy = (int)(t % Ho);
@@ -35,37 +36,53 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const T* __restrict__ in,
   constexpr int NC = (PX - 1) * STRIDE + 3;
   const int iy0 = oy * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
 
-  f32x4 wt[9];
+  float acc[PX][V];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) wt[k] = *reinterpret_cast<const f32x4*>(w + k * C + c);
-  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
-  f32x4 acc[PX];
+  for (int e = 0; e < V; ++e) {
+    const float bv = bias[c + e];
 #pragma unroll
-  for (int p = 0; p < PX; ++p) acc[p] = bv;
+    for (int p = 0; p < PX; ++p) acc[p][e] = bv;
+  }
 
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int iy = iy0 + ky;
     if (iy < 0 || iy >= H) continue;  // zero padding
+    float wt[3][V];                   // this row of taps only (keeps the register footprint small)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int e = 0; e < V; e += 4) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(w + (ky * 3 + kx) * C + c + e);
+        wt[kx][e] = x[0]; wt[kx][e + 1] = x[1]; wt[kx][e + 2] = x[2]; wt[kx][e + 3] = x[3];
+      }
     const T* row = in + ((size_t)b * H + iy) * (size_t)W * C + c;
-    f32x4 v[NC];
+    V16<T> v[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
       const int ix = ix0 + j;
-      v[j] = (ix >= 0 && ix < W) ? ld4(row + (size_t)ix * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ix >= 0 && ix < W) {
+        v[j] = ld16(row + (size_t)ix * C);
+      } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[j].v[e] = 0.f;
+      }
     }
 #pragma unroll
     for (int p = 0; p < PX; ++p)
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) acc[p] += v[p * STRIDE + kx] * wt[ky * 3 + kx];
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[p][e] += v[p * STRIDE + kx].v[e] * wt[kx][e];
   }
   T* orow = out + ((size_t)b * Ho + oy) * (size_t)Wo * C + c;
 #pragma unroll
   for (int p = 0; p < PX; ++p) {
     if (ox0 + p < Wo) {
-      f32x4 r = acc[p];
-      r.x = lrelu(r.x); r.y = lrelu(r.y); r.z = lrelu(r.z); r.w = lrelu(r.w);
-      st4(orow + (size_t)(ox0 + p) * C, r);
+      V16<T> r;
+#pragma unroll
+      for (int e = 0; e < V; ++e) r.v[e] = lrelu(acc[p][e]);
+      st16(orow + (size_t)(ox0 + p) * C, r);
     }
   }
 }
@@ -258,13 +275,14 @@ inline unsigned blocks_for(long long total) { return (unsigned)((total + 255) / 
 int launch_dw3x3(const void* in, const float* w, const float* bias, void* out, int batch, int h,
                  int wdt, int c, int stride, hipStream_t stream, int dtype) {
   CASYNC_REQUIRE(in && w && bias && out, "dw3x3: null pointer");
-  CASYNC_REQUIRE(batch > 0 && h > 0 && wdt > 0 && c > 0 && c % 4 == 0, "dw3x3: bad shape");
+  const int vec = 16 / dtype_size(dtype);   // channels per thread
+  CASYNC_REQUIRE(batch > 0 && h > 0 && wdt > 0 && c > 0 && c % vec == 0, "dw3x3: bad shape (C %% %d)", vec);
   CASYNC_REQUIRE(stride == 1 || stride == 2, "dw3x3: stride %d", stride);
   const int ho = (h + 2 - 3) / stride + 1, wo = (wdt + 2 - 3) / stride + 1;
   if (stride == 1) {
     constexpr int PX = 4;
     const int strips = (wo + PX - 1) / PX;
-    const long long total = (long long)batch * ho * strips * (c / 4);
+    const long long total = (long long)batch * ho * strips * (c / vec);
     DT_DISPATCH(dtype,
                 hipLaunchKernelGGL((dw3x3_kernel<float, 1, PX>), dim3(blocks_for(total)), dim3(256), 0, stream,
                                    (const float*)in, w, bias, (float*)out, h, wdt, c, ho, wo, strips, total),
@@ -273,7 +291,7 @@ int launch_dw3x3(const void* in, const float* w, const float* bias, void* out, i
   } else {
     constexpr int PX = 2;
     const int strips = (wo + PX - 1) / PX;
-    const long long total = (long long)batch * ho * strips * (c / 4);
+    const long long total = (long long)batch * ho * strips * (c / vec);
     DT_DISPATCH(dtype,
                 hipLaunchKernelGGL((dw3x3_kernel<float, 2, PX>), dim3(blocks_for(total)), dim3(256), 0, stream,
                                    (const float*)in, w, bias, (float*)out, h, wdt, c, ho, wo, strips, total),

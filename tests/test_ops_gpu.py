@@ -334,3 +334,18 @@ def test_ir_fused_with_upsample_bf16(bf16_ops, recipe_sd):
     ok(lib.casync_op_ir_fused_up(ptr(lod), c_lo, c_lo, ptr(cat), cin, ptr(w1), ptr(b1), ptr(wd), ptr(bd), ptr(w2),
                                  ptr(b2), ptr(out), 32, b, h, h, cin, 32, stream()))
     assert rel_err(nchw(out.float()), ref) < 2e-2
+
+
+@pytest.mark.parametrize("b,h,w,c,stride", [(2, 40, 40, 512, 1), (3, 20, 20, 256, 2), (2, 10, 10, 2048, 1), (1, 21, 13, 8, 2)])
+def test_dw3x3_bf16(bf16_ops, b, h, w, c, stride):
+    lib = bf16_ops
+    g = torch.Generator().manual_seed(c + h)
+    x = torch.randn(b, c, h, w, generator=g).bfloat16().float()
+    wt = torch.randn(c, 1, 3, 3, generator=g) / 3
+    bias = torch.randn(c, generator=g)
+    ref = F.leaky_relu(F.conv2d(x, wt, bias, stride, 1, 1, c), 0.01)
+    wp = wt.reshape(c, 9).T.contiguous().to(dev())
+    xd, bd = nhwc(x).bfloat16(), bias.to(dev())
+    out = torch.empty(b, ref.shape[2], ref.shape[3], c, device=dev(), dtype=torch.bfloat16)
+    ok(lib.casync_op_dw3x3(ptr(xd), ptr(wp), ptr(bd), ptr(out), b, h, w, c, stride, stream()))
+    assert rel_err(nchw(out.float()), ref) < 2 ** -8
