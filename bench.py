@@ -104,13 +104,22 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path to benchmark")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  Rehearsal hook: on a box with fewer GPUs than ranks (the 1-GPU dev box)
+    # ranks wrap around the visible devices and the weight broadcast goes over gloo, because RCCL
+    # refuses two ranks on one device; the code path is otherwise identical.
+    n_dev = torch.cuda.device_count()
+    shared = world > n_dev
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from calipsync_amd import arch, recipe, _lib
     from calipsync_amd.unet import Model
@@ -145,7 +154,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if shared else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(out).all()
@@ -214,7 +223,8 @@ def main():
                                    f"({'BASELINE configs[1]' if args.dtype == 'f32' else 'bf16 engine, BASELINE configs[2] family'}); "
                                    "frames sharded, weights broadcast once",
                        "global_batch": B * world, "parallelism": f"frames-dp{world}",
-                       "lanes_per_gpu": lanes},
+                       "lanes_per_gpu": lanes,
+                       **({"rehearsal": f"{world} ranks share {n_dev} GPU(s), gloo"} if shared else {})},
             "roofline": roofline,
             "whole_net": {"mfma_frac": round(per_gpu * work["flops"] / (MFMA_F32_PEAK_TF * 1e12), 4),
                           "hbm_frac_canonical": round(per_gpu * work["canonical_bytes_f32"] / (HBM_PEAK_GBS * 1e9), 4),

@@ -57,5 +57,11 @@ def broadcast_packed_weights(model_on_src, device: torch.device, src: int = 0,
     else:
         buf = torch.empty(n, dtype=torch.float32, device=device)
     if distributed:
-        dist.broadcast(buf, src=src, group=group)
+        if buf.is_cuda and dist.get_backend(group) == "gloo":
+            # rehearsal on a shared GPU: stage through host memory (gloo + device tensors is slow / partial)
+            host = buf.cpu()
+            dist.broadcast(host, src=src, group=group)
+            buf.copy_(host)
+        else:
+            dist.broadcast(buf, src=src, group=group)
     return buf

@@ -37,16 +37,19 @@ IR_SHAPES = [("up4.ir0", 64, 32, 1, 0, 160), ("up4.ir1", 32, 32, 1, 1, 160), ("u
 def bench_ir(args):
     lib = _lib.load()
     s = torch.cuda.current_stream().cuda_stream
+    bf = args.dtype == "bf16"
+    lib.casync_op_set_dtype(1 if bf else 0)
+    tdt = torch.bfloat16 if bf else torch.float32
     for name, cin, cout, stride, res, hw in IR_SHAPES:
         if args.only and args.only not in name:
             continue
         B, ce = args.batch, 2 * cin
         ho = hw // stride
-        x = torch.randn(B, hw, hw, cin, device=DEV)
-        w1, b1 = torch.randn(ce, cin, device=DEV) / cin ** 0.5, torch.randn(ce, device=DEV)
+        x = torch.randn(B, hw, hw, cin, device=DEV).to(tdt)
+        w1, b1 = (torch.randn(ce, cin, device=DEV) / cin ** 0.5).to(tdt), torch.randn(ce, device=DEV)
         wd, bd = torch.randn(9, ce, device=DEV) / 3, torch.randn(ce, device=DEV)
-        w2, b2 = torch.randn(cout, ce, device=DEV) / ce ** 0.5, torch.randn(cout, device=DEV)
-        out = torch.empty(B, ho, ho, cout, device=DEV)
+        w2, b2 = (torch.randn(cout, ce, device=DEV) / ce ** 0.5).to(tdt), torch.randn(cout, device=DEV)
+        out = torch.empty(B, ho, ho, cout, device=DEV, dtype=tdt)
 
         def fn():
             st = lib.casync_op_ir_fused(x.data_ptr(), cin, w1.data_ptr(), b1.data_ptr(), wd.data_ptr(), bd.data_ptr(),
@@ -56,7 +59,7 @@ def bench_ir(args):
         ms = time_ms(fn, args.iters)
         m_in, m_out = B * hw * hw, B * ho * ho
         flops = 2.0 * (m_in * cin * ce + 9 * m_out * ce + m_out * ce * cout)
-        byts = 4.0 * (m_in * cin + m_out * cout)
+        byts = x.element_size() * (m_in * cin + m_out * cout)
         print(f"{name:12s} cin={cin:3d} cout={cout:3d} s={stride} hw={hw:3d}  {ms:7.3f} ms  {flops / ms / 1e9:6.1f} TF  "
               f"{byts / ms / 1e6:7.1f} GB/s", flush=True)
 
