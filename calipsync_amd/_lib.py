@@ -38,6 +38,8 @@ _PROTOS = {
     "casync_load_weights_device": (C.c_int, [C.c_void_p, c_f32p, c_i64]),
     "casync_forward": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_void_p, c_i64,
                                  C.c_void_p]),
+    "casync_forward_windows": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.c_void_p, c_f32p, C.c_int,
+                                         C.c_void_p, c_i64, C.c_void_p]),
     "casync_tap": (c_i64, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, c_f32p, c_i64, C.c_void_p]),
     "casync_profile_forward": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_void_p,
                                          c_i64, C.c_void_p, C.POINTER(KernelTime), C.c_int]),

@@ -277,6 +277,11 @@ struct Plan {
   int B;
   hipStream_t aux = nullptr;          // engine's second stream (null = no overlap)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // audio source: either the NCHW windows tensor (`audio`) or, when win_feat is set, the whole
+  // HuBERT feature array + per-frame indices, gathered on the device (infer_api.py:99-145)
+  const float* win_feat = nullptr;
+  int win_steps = 0;
+  const int* win_idx = nullptr;
   bool fuse_ir = env_int("CASYNC_FUSE_IR", 1) != 0;      // A/B switch for the fused IR kernel
   bool fuse_up = env_int("CASYNC_FUSE_UP", 1) != 0;      // fold the bilinear upsample into up3/up4
   int fuse_min_hw = env_int("CASYNC_FUSE_MIN_HW", 32);   // fuse stages at least this large
@@ -353,8 +358,12 @@ struct Plan {
     }
     // ---------------- audio encoder (module/unet.py:177-194)
     Ptr AE1 = ar[A::AE1], AE2 = ar[A::AE2];
-    r.run("audio.nchw_to_nhwc", kname("nchw_to_nhwc_kernel").c_str(), 0, (4.0 + dtype_size(dt())) * B * 32768,
-          [&] { return launch_nchw_to_nhwc(audio, ar[A::A0], B, 32, 1024, r.s, dt()); });
+    if (win_feat)
+      r.run("audio.window_gather", kname("audio_window_gather_kernel").c_str(), 0, (4.0 + dtype_size(dt())) * B * 32768,
+            [&] { return launch_audio_window_gather(win_feat, win_steps, win_idx, ar[A::A0], B, r.s, dt()); });
+    else
+      r.run("audio.nchw_to_nhwc", kname("nchw_to_nhwc_kernel").c_str(), 0, (4.0 + dtype_size(dt())) * B * 32768,
+            [&] { return launch_nchw_to_nhwc(audio, ar[A::A0], B, 32, 1024, r.s, dt()); });
     ir(kAudio[0], ar[A::A0], 32, ar[A::AC1], 64, AE1, AE2);
     ir(kAudio[1], ar[A::AC1], 64, ar[A::AC2], 128, AE1, AE2);
     r.run("audio.conv3.im2col", kname("im2col3x3_kernel").c_str(), 0, dtype_size(dt()) * (double)B * (131072 + 256 * 1152), [&] {
@@ -616,8 +625,26 @@ static int ensure_streams(casync_handle h) {
   return CASYNC_OK;
 }
 
+static int forward_impl(casync_handle h, const float* x, const float* a, const float* feat, int n_steps,
+                        const int* idx, float* out, int batch, void* ws, int64_t ws_bytes,
+                        casync_stream stream);
+
 int casync_forward(casync_handle h, const float* x, const float* a, float* out, int batch, void* ws,
                    int64_t ws_bytes, casync_stream stream) {
+  return forward_impl(h, x, a, nullptr, 0, nullptr, out, batch, ws, ws_bytes, stream);
+}
+
+int casync_forward_windows(casync_handle h, const float* x, const float* features, int n_steps,
+                           const int32_t* frame_idx, float* out, int batch, void* ws, int64_t ws_bytes,
+                           casync_stream stream) {
+  CASYNC_REQUIRE(features && frame_idx && n_steps > 0, "forward_windows: null features / indices");
+  CASYNC_REQUIRE(((uintptr_t)features % 16) == 0, "forward_windows: features must be 16-B aligned");
+  return forward_impl(h, x, features, features, n_steps, frame_idx, out, batch, ws, ws_bytes, stream);
+}
+
+static int forward_impl(casync_handle h, const float* x, const float* a, const float* feat, int n_steps,
+                        const int* idx, float* out, int batch, void* ws, int64_t ws_bytes,
+                        casync_stream stream) {
   int st = check_forward_args(h, x, a, out, batch, ws, ws_bytes);
   if (st != CASYNC_OK) return st;
   hipStream_t caller = (hipStream_t)stream;
@@ -644,7 +671,13 @@ int casync_forward(casync_handle h, const float* x, const float* a, float* out, 
       p.ev_fork = h->ev_fork[l];
       p.ev_join = h->ev_join[l];
     }
-    p.forward(x + (size_t)b0 * 6 * 160 * 160, a + (size_t)b0 * 32 * 32 * 32, out + (size_t)b0 * 3 * 160 * 160);
+    if (feat) {
+      p.win_feat = feat;
+      p.win_steps = n_steps;
+      p.win_idx = idx + b0;
+    }
+    p.forward(x + (size_t)b0 * 6 * 160 * 160, feat ? nullptr : a + (size_t)b0 * 32 * 32 * 32,
+              out + (size_t)b0 * 3 * 160 * 160);
     if (r.status != CASYNC_OK) return r.status;
     if (l) CASYNC_CHECK_HIP(hipEventRecord(h->ev_done[l], r.s));
     b0 += bl;

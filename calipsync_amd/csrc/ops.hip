@@ -158,6 +158,37 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
   st4(out + ((size_t)b * HW + p) * C + c, v);
 }
 
+// ---------------------------------------------------------------- HuBERT window gather
+// Reference: FrameSynthesizer._get_audio_features (infer_api.py:99-145): for video frame index i
+// the window is features[i-8 : i+8] of the [T, 2, 1024] HuBERT array, zero-padded past either
+// end, flattened and reshaped to (32, 32, 32) = [c][y][x].  Flat position f = c*1024 + y*32 + x
+// lies in window entry f/2048, half (f%2048)/1024, so channel c = 2*entry + half and pixel
+// p = f%1024:  audio[b][c][p] = features[idx[b] - 8 + c/2][c%2][p].  This writes the engine's NHWC
+// audio input [B][1024][32] directly, so neither the B x 128 KB host windows nor the NCHW->NHWC
+// pass exist.  Thread = (b, p, 4 channels).
+template <typename T>
+__global__ __launch_bounds__(256) void audio_window_gather_kernel(const float* __restrict__ feat, int n_steps,
+                                                                  const int* __restrict__ idx,
+                                                                  T* __restrict__ out, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int p = (int)(i % 1024);
+  long long t = i / 1024;
+  const int c = (int)(t % 8) * 4;
+  const int b = (int)(t / 8);
+  const int t0 = idx[b] - 8 + c / 2;   // c is a multiple of 4: entries t0 (c, c+1) and t0+1 (c+2, c+3)
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (t0 >= 0 && t0 < n_steps) {
+    v.x = feat[(size_t)t0 * 2048 + p];
+    v.y = feat[(size_t)t0 * 2048 + 1024 + p];
+  }
+  if (t0 + 1 >= 0 && t0 + 1 < n_steps) {
+    v.z = feat[(size_t)(t0 + 1) * 2048 + p];
+    v.w = feat[(size_t)(t0 + 1) * 2048 + 1024 + p];
+  }
+  st4(out + ((size_t)b * 1024 + p) * 32 + c, v);
+}
+
 // ---------------------------------------------------------------- inc (6 -> 12 -> dw -> 32)
 // Block = 8 rows x 32 columns of one frame.  Phase A: 1x1 expand (+bias, LReLU) of the
 // 10 x 34 halo into LDS, zero where the halo leaves the image (the depthwise conv pads the
@@ -338,6 +369,19 @@ int launch_nchw_to_nhwc(const float* in, void* out, int batch, int c, int hw, hi
                                  (float*)out, c, hw, total),
               hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(blocks_for(total)), dim3(256), 0, stream, in,
                                  (bf16_t*)out, c, hw, total));
+  CASYNC_CHECK_HIP(hipGetLastError());
+  return CASYNC_OK;
+}
+
+int launch_audio_window_gather(const float* features, int n_steps, const int* idx_dev, void* out, int batch,
+                               hipStream_t stream, int dtype) {
+  CASYNC_REQUIRE(features && idx_dev && out && batch > 0 && n_steps > 0, "audio_window_gather: bad args");
+  const long long total = (long long)batch * 8 * 1024;
+  DT_DISPATCH(dtype,
+              hipLaunchKernelGGL(audio_window_gather_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream,
+                                 features, n_steps, idx_dev, (float*)out, total),
+              hipLaunchKernelGGL(audio_window_gather_kernel<bf16_t>, dim3(blocks_for(total)), dim3(256), 0, stream,
+                                 features, n_steps, idx_dev, (bf16_t*)out, total));
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }

@@ -220,6 +220,43 @@ class Model(nn.Module):
                                                   stream), "casync_forward")
         return out
 
+    @torch.no_grad()
+    def forward_windows(self, x: torch.Tensor, features: torch.Tensor, frame_indices) -> torch.Tensor:
+        """Forward with the HuBERT windows gathered on the device.
+
+        ``features``: the clip's whole HuBERT array ``[T, 2, 1024]`` fp32 on the model's device
+        (uploaded once); ``frame_indices``: the video frame index of every batch entry.  Entry b
+        sees ``features[i-8:i+8]`` zero-padded past both ends and reshaped to ``(32,32,32)`` --
+        the window ``FrameSynthesizer._get_audio_features`` (reference infer_api.py:99-145)
+        builds on the host, bit for bit.  Equivalent to ``forward(x, windows)``."""
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("casync_amd.Model runs on a ROCm device only (no CPU fallback)")
+        if features.dim() != 3 or tuple(features.shape[1:]) != (2, 1024) or features.dtype != torch.float32:
+            raise RuntimeError(f"features must be float32 [T,2,1024], got {tuple(features.shape)} {features.dtype}")
+        if features.device != dev or x.device != dev:
+            raise RuntimeError(f"x and features must be on {dev}")
+        idx = torch.as_tensor(frame_indices, dtype=torch.int32).to(dev).contiguous()
+        batch = x.shape[0]
+        if idx.dim() != 1 or idx.numel() != batch:
+            raise RuntimeError("frame_indices must have one entry per batch element")
+        if x.dim() != 4 or tuple(x.shape[1:]) != (6, arch.FACE_HW, arch.FACE_HW) or x.dtype != torch.float32:
+            raise RuntimeError(f"x must be float32 [B,6,160,160], got {tuple(x.shape)}")
+        if self.training:
+            raise RuntimeError("the MI355X engine implements the eval-mode forward only; call .eval()")
+        if batch == 0:
+            return torch.empty((0, 3, arch.FACE_HW, arch.FACE_HW), dtype=torch.float32, device=dev)
+        x, features = x.contiguous(), features.contiguous()
+        with torch.cuda.device(dev):
+            self._ensure_weights(dev)
+            ws = self._ws(batch, dev)
+            out = torch.empty((batch, 3, arch.FACE_HW, arch.FACE_HW), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(_lib.load().casync_forward_windows(
+                self._engine, x.data_ptr(), features.data_ptr(), features.shape[0], idx.data_ptr(),
+                out.data_ptr(), batch, ws.data_ptr(), ws.numel(), stream), "casync_forward_windows")
+        return out
+
     # ------------------------------------------------------------------ debugging / measurement
     @torch.no_grad()
     def tap(self, name: str, batch: int) -> torch.Tensor:

@@ -85,6 +85,15 @@ int  casync_forward(casync_handle h, const float* x_dev, const float* audio_dev,
                     float* out_dev, int batch, void* workspace_dev,
                     int64_t workspace_bytes, casync_stream stream);
 
+/* Same forward, but the HuBERT windows are gathered on the device: `features_dev` is the whole
+ * [n_steps, 2, 1024] fp32 feature array of the clip (uploaded once), frame_idx_dev[b] the video
+ * frame index of batch entry b; entry b sees features[idx-8 : idx+8], zero-padded past both
+ * ends, reshaped to (32,32,32) -- exactly FrameSynthesizer._get_audio_features
+ * (infer_api.py:99-145), without the B x 128 KB host windows and their H2D copy.           */
+int  casync_forward_windows(casync_handle h, const float* x_dev, const float* features_dev,
+                            int n_steps, const int32_t* frame_idx_dev, float* out_dev, int batch,
+                            void* workspace_dev, int64_t workspace_bytes, casync_stream stream);
+
 /* Debug taps: copy a named NHWC intermediate of the LAST forward (same batch,
  * same workspace) into dst_dev; returns its per-frame float count or <0.
  * Names: x1 x2 x3 x4 x5 a tx kx fuse u1 u2 u3 u4 att0..att3 audio_conv2..5   */
