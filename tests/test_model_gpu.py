@@ -144,3 +144,22 @@ def test_bf16_frames_independent(net_bf16):
     full = net_bf16(xt, at)
     part = net_bf16(xt[3:4].contiguous(), at[3:4].contiguous())
     assert torch.equal(full[3:4], part)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_full_size_batch_properties(recipe_sd, precision):
+    """BASELINE configs[2]/[3] per-GPU size (512 frames): no oracle run at this size; instead the
+    size-independent properties -- every frame equals its own single-frame forward bit for bit
+    (frames independent, lanes / tiling batch-invariant), duplicates agree, outputs in (0,1)."""
+    m = Model(6, "hubert", precision=precision).to("cuda:0")
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe_sd.items()})
+    x16, a16 = recipe.make_inputs(16)
+    x = torch.from_numpy(x16).cuda().repeat(32, 1, 1, 1)          # 512 frames, 16 distinct
+    a = torch.from_numpy(a16).cuda().repeat(32, 1, 1, 1)
+    out = m(x, a)
+    assert out.shape == (512, 3, 160, 160) and torch.isfinite(out).all()
+    assert out.min() > 0 and out.max() < 1
+    assert torch.equal(out[:16], out[256:272]) and torch.equal(out[5], out[16 * 31 + 5])   # duplicates, both lanes
+    for i in (0, 7, 15):
+        single = m(x[i:i + 1].contiguous(), a[i:i + 1].contiguous())
+        assert torch.equal(single[0], out[i]), i
