@@ -223,6 +223,200 @@ __global__ __launch_bounds__(64 * WM * WN) void pw_gemm_kernel(const T* __restri
   }
 }
 
+// =====================================================================================
+// Direct-to-LDS variant: the k-tiles arrive by global_load_lds_dwordx4 (no register staging, no
+// ds_write) into an NST-deep ring, NST-1 tiles ahead of the MFMAs.  A bf16 k-tile is only ~512 MFMA
+// cycles per wave, less than the L2/HBM latency, so the one-tile register prefetch of the kernel
+// above cannot cover it; the ring can.  An LDS-DMA wave-instruction writes base + lane*16 linearly
+// (8 rows x 128 B), so rows are unpadded and the 16-B columns are XOR-swizzled through the
+// per-lane SOURCE address: LDS column p of row r holds global column p ^ ((r>>1)&7); readers
+// apply the same key (16 consecutive rows of one column then hit 16 different bank slots).
+// Sync per k-tile: counted s_waitcnt vmcnt (this wave's part of tile kt has landed) -> raw
+// s_barrier (everyone's part has landed, and everyone is done reading the stage about to be
+// refilled) -> issue tile kt+NST-1 -> MFMAs on tile kt.  One barrier per k-tile, loads stay in
+// flight across it.
+// =====================================================================================
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int BM, int BN, int WM, int WN, int NST>
+__global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__ A, int lda,
+                                                           const T* __restrict__ W, T* __restrict__ C,
+                                                           int ldc, int M, int N, int K, int n_ntiles,
+                                                           int nwg, GemmEpilogue epi) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int BK = ROWB / (int)sizeof(T);
+  constexpr int E16 = 16 / (int)sizeof(T);
+  constexpr int ROWS = BM + BN;
+  constexpr int STAGE = ROWS * ROWB;          // bytes per ring stage
+  constexpr int LPT = ROWS / 32;              // LDS-DMA instructions per wave per k-tile (8 rows each, 4 waves)
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int LDC_S = BN + 4;
+  static_assert((size_t)NST * STAGE >= (size_t)BM * LDC_S * sizeof(float), "ring must hold the C tile");
+  static_assert(LPT * (NST - 1) < 64, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) char ring[];
+  float* Cs = reinterpret_cast<float*>(ring);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int r32 = lane & 31, kh = lane >> 5;
+  const int nk = K / BK;
+  const int lrow8 = lane >> 3, lcol = lane & 7;
+
+  // epilogue constants
+  constexpr int TPR = BN / 4, RPP = 256 / TPR;
+  const int c4 = (tid % TPR) * 4, rr = tid / TPR;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
+
+  for (int tile = blockIdx.x; tile < nwg; tile += gridDim.x) {
+    int m0, n0;
+    {
+      const int q = nwg >> 3, r = nwg & 7, xcd = tile & 7, idx = tile >> 3;
+      const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+      const int mt = bid / n_ntiles;
+      m0 = mt * BM;
+      n0 = (bid - mt * n_ntiles) * BN;
+    }
+    // this lane's source pointer for each of the wave's LPT instructions (k-tile 0)
+    const T* src[LPT];
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) {
+      const int r = (j * 4 + wave) * 8 + lrow8;             // row inside the stage: [0,BM) = A, [BM,ROWS) = W
+      const int cs = lcol ^ ((r >> 1) & 7);                 // swizzled source column
+      if (r < BM) {
+        int row = m0 + r;
+        row = row < M ? row : M - 1;
+        src[j] = A + (size_t)row * lda + cs * E16;
+      } else {
+        src[j] = W + (size_t)(n0 + r - BM) * K + cs * E16;
+      }
+    }
+    auto issue = [&](int kt) {
+      char* st = ring + (kt % NST) * STAGE;
+#pragma unroll
+      for (int j = 0; j < LPT; ++j)
+        __builtin_amdgcn_global_load_lds(
+            (const void __attribute__((address_space(1)))*)(src[j] + (size_t)kt * BK),
+            (void __attribute__((address_space(3)))*)(st + (j * 4 + wave) * 8 * ROWB), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+      if (s < nk) issue(s);
+
+    // fragment addressing: row byte offset and swizzle key are loop-invariant per lane
+    int a_off[TM], a_key[TM], b_off[TN], b_key[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int r = wm * (BM / WM) + i * 32 + r32;
+      a_off[i] = r * ROWB;
+      a_key[i] = (r >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int r = BM + wn * (BN / WN) + j * 32 + r32;
+      b_off[j] = r * ROWB;
+      b_key[j] = (r >> 1) & 7;
+    }
+
+    for (int kt = 0; kt < nk; ++kt) {
+      // tiles kt+1 .. kt+NST-2 may stay in flight (fewer near the end of the k loop)
+      const int ahead = nk - 1 - kt;
+      if (NST >= 4 && ahead >= 2) wait_vmcnt<(NST >= 4 ? 2 : 0) * LPT>();
+      else if (NST >= 3 && ahead >= 1) wait_vmcnt<LPT>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + NST - 1 < nk) issue(kt + NST - 1);
+      const char* st = ring + (kt % NST) * STAGE;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[i] = *reinterpret_cast<const f32x4*>(st + a_off[i] + (((2 * g + kh) ^ a_key[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          fb[j] = *reinterpret_cast<const f32x4*>(st + b_off[j] + (((2 * g + kh) ^ b_key[j]) << 4));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = MfmaK<T>::run(fa[i], fb[j], acc[i][j]);
+      }
+    }
+    __syncthreads();   // everything landed and consumed: the ring becomes the C tile
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float* cbase = Cs + (wm * (BM / WM) + i * 32 + 4 * kh) * LDC_S + wn * (BN / WN) + j * 32 + r32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cbase[((r & 3) + 8 * (r >> 2)) * LDC_S] = acc[i][j][r];
+      }
+    __syncthreads();
+
+    const int n = n0 + c4;
+    const f32x4 bias = epi.bias ? *reinterpret_cast<const f32x4*>(epi.bias + n) : zero;
+    const f32x4 pscale = epi.pre_scale ? *reinterpret_cast<const f32x4*>(epi.pre_scale + n) : one;
+    const f32x4 as = epi.aff_s ? *reinterpret_cast<const f32x4*>(epi.aff_s + n) : one;
+    const f32x4 at = epi.aff_s ? *reinterpret_cast<const f32x4*>(epi.aff_t + n) : zero;
+#pragma unroll 4
+    for (int p = 0; p < BM / RPP; ++p) {
+      const int row = rr + RPP * p, m = m0 + row;
+      if (m >= M) break;
+      f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC_S + c4) + bias;
+      if (epi.pre_res) v += pscale * ld4(static_cast<const T*>(epi.pre_res) + (size_t)m * epi.ld_pre + n);
+      if (epi.act) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
+      if (epi.post_res) v += ld4(static_cast<const T*>(epi.post_res) + (size_t)m * epi.ld_post + n);
+      if (epi.aff_s && !epi.aff_on_acc) {
+        v = v * as + at;
+        v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w);
+      }
+      st4(C + (size_t)m * ldc + n, v);
+      if (epi.acc_out) {
+        f32x4 s = ld4(static_cast<const T*>(epi.acc_in) + (size_t)m * epi.ld_acc + n) + v;
+        if (epi.aff_s && epi.aff_on_acc) {
+          s = s * as + at;
+          s.x = lrelu(s.x); s.y = lrelu(s.y); s.z = lrelu(s.z); s.w = lrelu(s.w);
+        }
+        st4(static_cast<T*>(epi.acc_out) + (size_t)m * epi.ld_acc + n, s);
+      }
+    }
+    __syncthreads();   // C tile consumed before the next tile's loads overwrite the ring
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NST>
+int launch_glds_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, int k,
+                  const GemmEpilogue& epi, hipStream_t stream) {
+  constexpr size_t lds = (size_t)NST * (BM + BN) * ROWB;
+  static bool attr_set = false;
+  auto kern = pw_gemm_glds_kernel<T, BM, BN, WM, WN, NST>;
+  if (!attr_set) {
+    CASYNC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int n_mtiles = (m + BM - 1) / BM, n_ntiles = n / BN;
+  const long long nwg = (long long)n_mtiles * n_ntiles;
+  CASYNC_REQUIRE(nwg < (1ll << 31), "gemm grid too large");
+  constexpr int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
+  const long long cap = 256ll * per_cu;
+  const unsigned grid = (unsigned)(nwg > cap ? cap : nwg);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a, lda, w, c, ldc, m, n, k, n_ntiles,
+                     (int)nwg, epi);
+  CASYNC_CHECK_HIP(hipGetLastError());
+  return CASYNC_OK;
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, int k,
                  const GemmEpilogue& epi, hipStream_t stream) {
@@ -248,9 +442,30 @@ int launch_cfg_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, i
   return CASYNC_OK;
 }
 
+inline int glds_mode() {
+  static const int v = [] { const char* e = getenv("CASYNC_GEMM_GLDS"); return e ? atoi(e) : 2; }();
+  return v;   // 0 = register-staged kernel only, 1 = LDS-DMA ring for bf16, 2 = for both types (default)
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, int n, int k,
                const GemmEpilogue& epi, hipStream_t stream, int dtype) {
+  constexpr int NST = (BM + BN) >= 256 ? 3 : ((BM + BN) >= 192 ? 3 : 4);
+  // The 128x128 ring (96 KB) leaves room for one workgroup per CU only: use it when the launch
+  // has at most one tile per CU anyway (then its deeper pipeline wins), else the register-staged
+  // kernel with two co-resident workgroups.  The smaller tiles always take the ring.
+  const long long tiles = (long long)((m + BM - 1) / BM) * (n / BN);
+  const bool ring_ok = (BM + BN) < 256 || tiles <= 256;
+  if constexpr (WM * WN == 4 && BN >= 64) {
+    if (ring_ok && dtype == DT_BF16 && glds_mode() >= 1)
+      return launch_glds_t<bf16_t, BM, BN, WM, WN, NST>(static_cast<const bf16_t*>(a), lda,
+                                                        static_cast<const bf16_t*>(w), static_cast<bf16_t*>(c),
+                                                        ldc, m, n, k, epi, stream);
+    if (ring_ok && dtype == DT_F32 && glds_mode() >= 2)
+      return launch_glds_t<float, BM, BN, WM, WN, NST>(static_cast<const float*>(a), lda,
+                                                       static_cast<const float*>(w), static_cast<float*>(c), ldc,
+                                                       m, n, k, epi, stream);
+  }
   if (dtype == DT_BF16)
     return launch_cfg_t<bf16_t, BM, BN, WM, WN>(static_cast<const bf16_t*>(a), lda, static_cast<const bf16_t*>(w),
                                                 static_cast<bf16_t*>(c), ldc, m, n, k, epi, stream);
@@ -297,7 +512,16 @@ const char* pw_gemm_kernel_name(int m, int n, int dtype) {
     case C64x64W2: cfg = "64, 64, 2, 1"; break;
     default: cfg = "128, 32, 4, 1"; break;
   }
-  snprintf(buf, sizeof(buf), "pw_gemm_kernel<%s, %s>", t, cfg);
+  const int id = pick_cfg(m, n);
+  const int bm = (id == C64x64 || id == C64x32 || id == C64x64W2) ? 64 : 128;
+  const int bn = id == C128x128 ? 128 : (id == C128x64 || id == C64x64 || id == C64x64W2 ? 64 : 32);
+  const long long tiles = (long long)((m + bm - 1) / bm) * (n / bn);
+  const bool ring = (id == C128x128 || id == C128x64 || id == C64x64) && (bm + bn < 256 || tiles <= 256) &&
+                    ((dtype == DT_BF16 && glds_mode() >= 1) || (dtype == DT_F32 && glds_mode() >= 2));
+  if (ring)
+    snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, %d>", t, cfg, bm + bn >= 192 ? 3 : 4);
+  else
+    snprintf(buf, sizeof(buf), "pw_gemm_kernel<%s, %s>", t, cfg);
   return buf;
 }
 
