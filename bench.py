@@ -186,9 +186,8 @@ def main():
         dom_name, dom = max(per.items(), key=lambda kv: kv[1]["ms"])
         tf = dom["flops"] / dom["ms"] / 1e9
         gbs = dom["bytes"] / dom["ms"] / 1e6
-        mfma_peak = MFMA_F32_PEAK_TF if args.dtype == "f32" or dom_name.startswith("ir_fused") else MFMA_BF16_PEAK_TF
-        mfma_bound = dom_name.startswith(("pw_gemm_kernel", "ir_fused_kernel")) and \
-            tf / mfma_peak >= gbs / HBM_PEAK_GBS
+        mfma_peak = MFMA_F32_PEAK_TF if args.dtype == "f32" else MFMA_BF16_PEAK_TF
+        mfma_bound = dom_name.startswith(("pw_gemm", "ir_fused")) and tf / mfma_peak >= gbs / HBM_PEAK_GBS
         roofline = {
             "kernel": dom_name,
             "bound": "mfma" if mfma_bound else "hbm",
@@ -204,6 +203,7 @@ def main():
                         "(profiles/r1_final_kernel_stats_lanes1.csv is rocprofv3 of that mode)",
         }
         work = arch.work_per_frame()
+        canon_bytes = work["canonical_bytes_f32"] // (1 if args.dtype == "f32" else 2)
         fps = world * B * args.steps / dt
         per_gpu = fps / world
         result = {
@@ -226,10 +226,10 @@ def main():
                        "lanes_per_gpu": lanes,
                        **({"rehearsal": f"{world} ranks share {n_dev} GPU(s), gloo"} if shared else {})},
             "roofline": roofline,
-            "whole_net": {"mfma_frac": round(per_gpu * work["flops"] / (MFMA_F32_PEAK_TF * 1e12), 4),
-                          "hbm_frac_canonical": round(per_gpu * work["canonical_bytes_f32"] / (HBM_PEAK_GBS * 1e9), 4),
+            "whole_net": {"mfma_frac": round(per_gpu * work["flops"] / (mfma_peak * 1e12), 4),
+                          "hbm_frac_canonical": round(per_gpu * canon_bytes / (HBM_PEAK_GBS * 1e9), 4),
                           "gflop_per_frame": round(work["flops"] / 1e9, 3),
-                          "canonical_mb_per_frame": round(work["canonical_bytes_f32"] / 1e6, 2)},
+                          "canonical_mb_per_frame": round(canon_bytes / 1e6, 2)},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd_np, args.cpu_seconds)
