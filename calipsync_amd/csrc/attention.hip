@@ -5,9 +5,11 @@
 //   out[i][c] = gamma * sum_j P[i][j] V[j][c] + res[i][c]
 //
 // Q, K, V come from the 1x1 projections (NHWC rows: position-major, channel contiguous).
-// One workgroup = 32 query rows of one frame (grid = B x 4); the 32x100 score tile lives in
-// LDS only.  QK^T and PV run on v_mfma_f32_32x32x2_f32; the row softmax is a 64-lane
-// shuffle reduction (two keys per lane).
+// One workgroup = 32 query rows x 128 value channels of one frame (grid = B x 4 x 4); the
+// 32x100 score tile lives in LDS only (recomputed per channel chunk: QK^T is ~10 % of the work).
+// The V chunk is fetched into registers at kernel entry and parked in LDS over the dead K tile,
+// so its HBM/L2 latency hides under the staging, QK^T and softmax phases.  QK^T and PV run on
+// v_mfma_f32_32x32x2_f32; the row softmax is a 64-lane shuffle reduction (two keys per lane).
 #include "common.h"
 
 namespace {
@@ -29,18 +31,36 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// LDS carve (floats): Q block, score tile, then K (QK^T phase) / V chunk (PV phase) share one area
+constexpr int VLD = 132;                       // V chunk rows: 128 channels + 4
+constexpr int oQ = 0, oS = oQ + 32 * QLD, oKV = oS + 32 * SLD;
+constexpr int KV_FLOATS = 128 * QLD > NP * VLD ? 128 * QLD : NP * VLD;
+constexpr int ATT_LDS_BYTES = (oKV + KV_FLOATS) * 4;
+constexpr int VREGS = (NP * 128 / 4 + 255) / 256;   // float4 per thread holding the V chunk in flight
+
 template <typename T>
 __global__ __launch_bounds__(256) void cross_attention_kernel(
     const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
     const T* __restrict__ v, int ldv, const T* __restrict__ res, int ld_res,
     const float* __restrict__ gamma, T* __restrict__ out, int ld_out) {
-  __shared__ __attribute__((aligned(16))) float Qs[32 * QLD];
-  __shared__ __attribute__((aligned(16))) float Ks[128 * QLD];
-  __shared__ __attribute__((aligned(16))) float Ss[32 * SLD];
-  const int b = blockIdx.x, qb = blockIdx.y;
+  extern __shared__ __attribute__((aligned(16))) float att_lds[];
+  float* Qs = att_lds + oQ;
+  float* Ss = att_lds + oS;
+  float* Ks = att_lds + oKV;   // [128][QLD] during QK^T
+  float* Vs = att_lds + oKV;   // [100][VLD] during PV (after the scores are done with K)
+  const int b = blockIdx.x, qb = blockIdx.y, cz = blockIdx.z;   // frame, 32-query block, 128-channel chunk
   const size_t row0 = (size_t)b * NP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, kh = lane >> 5;
+
+  // ---- the V chunk [100 keys][128 channels] starts its trip from HBM/L2 now and is parked in
+  //      registers until K is dead (it arrives under the staging, QK^T and softmax phases) ----
+  f32x4 vreg[VREGS];
+#pragma unroll
+  for (int j = 0; j < VREGS; ++j) {
+    const int idx = tid + 256 * j;                // float4 index: key = idx/32, 4 channels at (idx%32)*4
+    if (idx < NP * 32) vreg[j] = ld4(v + (row0 + (idx >> 5)) * ldv + cz * 128 + (idx & 31) * 4);
+  }
 
   // ---- stage Q block and all K rows (rows >= 100 are zero) ----
   {
@@ -82,9 +102,14 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(
       Ss[i * SLD + wave * 32 + r32] = acc[r];
     }
   }
-  __syncthreads();
+  __syncthreads();   // scores complete, K dead
 
-  // ---- row softmax over the 100 keys: wave w owns rows 8w .. 8w+7 ----
+  // ---- park V in LDS (over K) and run the row softmax: wave w owns rows 8w .. 8w+7 ----
+#pragma unroll
+  for (int j = 0; j < VREGS; ++j) {
+    const int idx = tid + 256 * j;
+    if (idx < NP * 32) *reinterpret_cast<f32x4*>(Vs + (idx >> 5) * VLD + (idx & 31) * 4) = vreg[j];
+  }
 #pragma unroll
   for (int rr = 0; rr < 8; ++rr) {
     float* srow = Ss + (wave * 8 + rr) * SLD;
@@ -100,37 +125,28 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(
   }
   __syncthreads();
 
-  // ---- out = P V: wave w owns value channels 128w .. 128w+127 (4 MFMA column tiles) ----
-  f32x16 acc[4];
+  // ---- out = P V: wave w owns channels 32w .. 32w+31 of this block's 128-channel chunk ----
+  f32x16 acc;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const float* pa = Ss + r32 * SLD + 4 * kh;
-  const T* vb = v + wave * 128 + r32;
-#pragma unroll 1
+  const float* vb = Vs + wave * 32 + r32;
+#pragma unroll
   for (int g = 0; g < 13; ++g) {  // 13 groups of 8 keys cover 0..103; P is zero past 99
     const f32x4 fa = *reinterpret_cast<const f32x4*>(pa + 8 * g);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       int key = 8 * g + 4 * kh + s;
-      key = key < NP ? key : NP - 1;  // stay inside this frame's rows (weight is 0 there)
-      const T* vrow = vb + (row0 + key) * ldv;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], (float)vrow[j * 32], acc[j], 0, 0, 0);
+      key = key < NP ? key : NP - 1;  // stay inside the staged rows (weight is 0 there)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], vb[key * VLD], acc, 0, 0, 0);
     }
   }
   const float gam = gamma[0];
+  const int c = cz * 128 + wave * 32 + r32;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = wave * 128 + j * 32 + r32;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (qi < NP)
-        out[(row0 + qi) * ld_out + c] = (T)(gam * acc[j][r] + (float)res[(row0 + qi) * ld_res + c]);
-    }
+  for (int r = 0; r < 16; ++r) {
+    const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+    if (qi < NP) out[(row0 + qi) * ld_out + c] = (T)(gam * acc[r] + (float)res[(row0 + qi) * ld_res + c]);
   }
 }
 
@@ -145,13 +161,22 @@ int launch_cross_attention(const void* q, int ldq, const void* k, int ldk, const
                      ld_res >= CV && ld_out >= CV,
                  "cross_attention: bad leading dimensions");
   CASYNC_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0, "cross_attention: Q/K alignment");
+  static bool attr_set = false;
+  if (!attr_set) {
+    CASYNC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cross_attention_kernel<float>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES));
+    CASYNC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cross_attention_kernel<bf16_t>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES));
+    attr_set = true;
+  }
+  const dim3 grid(batch, 4, 4);   // frame x 32-query block x 128-channel chunk
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL(cross_attention_kernel<bf16_t>, dim3(batch, 4), dim3(256), 0, stream, (const bf16_t*)q, ldq,
-                       (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)res, ld_res, gamma_dev,
+    hipLaunchKernelGGL(cross_attention_kernel<bf16_t>, grid, dim3(256), ATT_LDS_BYTES, stream, (const bf16_t*)q,
+                       ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)res, ld_res, gamma_dev,
                        (bf16_t*)out, ld_out);
   else
-    hipLaunchKernelGGL(cross_attention_kernel<float>, dim3(batch, 4), dim3(256), 0, stream, (const float*)q, ldq,
-                       (const float*)k, ldk, (const float*)v, ldv, (const float*)res, ld_res, gamma_dev,
+    hipLaunchKernelGGL(cross_attention_kernel<float>, grid, dim3(256), ATT_LDS_BYTES, stream, (const float*)q,
+                       ldq, (const float*)k, ldk, (const float*)v, ldv, (const float*)res, ld_res, gamma_dev,
                        (float*)out, ld_out);
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
