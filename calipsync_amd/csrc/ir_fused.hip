@@ -521,14 +521,17 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
   for (int ch = 0; ch < NCH; ++ch) {
     const char* wb = sW + (ch & 1) * GB::WBUF;
     const float* wf = reinterpret_cast<const float*>(wb + GB::wWd);   // [9][32] taps, then b1[32], bd[32]
-    // ---- P1: expand GEMM over the halo, bias preloaded into the accumulators ----
+    // ---- P1: expand GEMM over the halo.  The weight chunk is the MFMA A operand and the pixels
+    //      the B operand, so D[channel][pixel]: a lane ends up with 4 CONSECUTIVE channels
+    //      (rows 4q..4q+3) of ONE pixel (column l&15) -> one packed 8-byte LDS write per tile, one
+    //      border mask per tile.  Bias (per channel = per accumulator row) is the initial value. ----
     {
       f32x4 acc[G::MT1][2];
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
-        const float bias = wf[9 * 32 + 16 * n + l15];
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(wf + 9 * 32 + 16 * n + 4 * q);
 #pragma unroll
-        for (int i = 0; i < G::MT1; ++i) acc[i][n] = f32x4{bias, bias, bias, bias};
+        for (int i = 0; i < G::MT1; ++i) acc[i][n] = bias;
       }
 #pragma unroll
       for (int g = 0; g < GB::KG; ++g) {
@@ -539,25 +542,27 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
 #pragma unroll
         for (int i = 0; i < G::MT1; ++i)
 #pragma unroll
-          for (int n = 0; n < 2; ++n) acc[i][n] = mfma16b(fa[i][g], fb[n], acc[i][n]);
+          for (int n = 0; n < 2; ++n) acc[i][n] = mfma16b(fb[n], fa[i][g], acc[i][n]);
       }
 #pragma unroll
-      for (int i = 0; i < G::MT1; ++i)
+      for (int i = 0; i < G::MT1; ++i) {
+        const int hp = 16 * (wave * G::MT1 + i) + l15;     // this lane's halo pixel
+        if (hp < G::HP) {
+          float m = 1.f;
+          if (border) {
+            const int hy = hp / G::IW, hx = hp - hy * G::IW;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            m = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? 1.f : 0.f;
+          }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int hp = 16 * (wave * G::MT1 + i) + 4 * q + r;
-          if (hp < G::HP) {
-            float m = 1.f;
-            if (border) {
-              const int hy = hp / G::IW, hx = hp - hy * G::IW;
-              const int iy = iy0 + hy, ix = ix0 + hx;
-              m = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? 1.f : 0.f;
-            }
+          for (int n = 0; n < 2; ++n) {
+            bf16x4 v;
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
-              reinterpret_cast<bf16_t*>(sE)[hp * CC + 16 * n + l15] = (bf16_t)(m * lrelu_max(acc[i][n][r]));
+            for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(m * lrelu_max(acc[i][n][r]));
+            *reinterpret_cast<bf16x4*>(sE + (hp * CC + 16 * n + 4 * q) * 2) = v;
           }
         }
+      }
     }
     __syncthreads();  // E complete; every wave is done with the previous chunk's P3
     if (ch + 1 < NCH) {
@@ -602,7 +607,8 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
     }
     __syncthreads();  // D complete (and the parked weights are visible)
 
-    // ---- P3: project GEMM, one 32-deep MFMA per output tile and chunk ----
+    // ---- P3: project GEMM, one 32-deep MFMA per output tile and chunk (W2c = A operand,
+    //      pixels = B operand: acc3[i][n] holds channels 16n+4q..+3 of pixel 16(wave*MT3+i)+l15) ----
     {
       bf16x8 fd[G::MT3], fb[G::NT3];
 #pragma unroll
@@ -614,12 +620,13 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
 #pragma unroll
       for (int i = 0; i < G::MT3; ++i)
 #pragma unroll
-        for (int n = 0; n < G::NT3; ++n) acc3[i][n] = mfma16b(fd[i], fb[n], acc3[i][n]);
+        for (int n = 0; n < G::NT3; ++n) acc3[i][n] = mfma16b(fb[n], fd[i], acc3[i][n]);
     }
   }
   __syncthreads();
 
-  // ---- epilogue: + b2, LReLU -> fp32 LDS staging (32 columns at a time) -> coalesced bf16 rows ----
+  // ---- epilogue: + b2, LReLU -> fp32 LDS staging (32 columns at a time, one float4 per lane and
+  //      tile) -> coalesced bf16 rows ----
   float* sO = reinterpret_cast<float*>(smem_b);
   bf16_t* outb = out + (size_t)b * Ho * Wo * ld_out;
 #pragma unroll
@@ -627,14 +634,14 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
     if (n0) __syncthreads();
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
-      const float bias = b2[16 * (n0 + nn) + l15];
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(b2 + 16 * (n0 + nn) + 4 * q);
 #pragma unroll
-      for (int i = 0; i < G::MT3; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int p = 16 * (wave * G::MT3 + i) + 4 * q + r;
-          sO[p * G::LDO + 16 * nn + l15] = lrelu_max(acc3[i][n0 + nn][r] + bias);
-        }
+      for (int i = 0; i < G::MT3; ++i) {
+        const int p = 16 * (wave * G::MT3 + i) + l15;
+        f32x4 v = acc3[i][n0 + nn] + bias;
+        v.x = lrelu_max(v.x); v.y = lrelu_max(v.y); v.z = lrelu_max(v.z); v.w = lrelu_max(v.w);
+        *reinterpret_cast<f32x4*>(sO + p * G::LDO + 16 * nn + 4 * q) = v;
+      }
     }
     __syncthreads();
     for (int idx = tid; idx < G::OP * 8; idx += 256) {
