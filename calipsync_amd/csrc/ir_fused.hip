@@ -230,14 +230,17 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
 #pragma unroll 1
   for (int ch = 0; ch < NCH; ++ch) {
     const float* wb = sW + (ch & 1) * G::WBUF;
-    // ---- P1: expand GEMM over the halo, [HPP x CIN] x [CIN x CC], bias preloaded into acc ----
+    // ---- P1: expand GEMM over the halo.  The weight chunk is the MFMA A operand and the pixels
+    //      the B operand (the register fragments serve either role), so D[channel][pixel]: a lane
+    //      ends up with 4 CONSECUTIVE channels (rows 4q..4q+3) of ONE pixel (column l&15) -> one
+    //      16-byte LDS write per tile and one border mask per tile.  Bias = initial accumulator. ----
     {
       f32x4 acc[G::MT1][G::NT1];
 #pragma unroll
       for (int n = 0; n < G::NT1; ++n) {
-        const float bias = wb[G::wB + 16 * n + l15];
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(wb + G::wB + 16 * n + 4 * q);
 #pragma unroll
-        for (int i = 0; i < G::MT1; ++i) acc[i][n] = f32x4{bias, bias, bias, bias};
+        for (int i = 0; i < G::MT1; ++i) acc[i][n] = bias;
       }
 #pragma unroll
       for (int g = 0; g < G::KG; ++g) {
@@ -250,24 +253,26 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
 #pragma unroll
           for (int i = 0; i < G::MT1; ++i)
 #pragma unroll
-            for (int n = 0; n < G::NT1; ++n) acc[i][n] = mfma16(fa[i][g][s], fb[n][s], acc[i][n]);
+            for (int n = 0; n < G::NT1; ++n) acc[i][n] = mfma16(fb[n][s], fa[i][g][s], acc[i][n]);
       }
 #pragma unroll
-      for (int i = 0; i < G::MT1; ++i)
+      for (int i = 0; i < G::MT1; ++i) {
+        const int hp = 16 * (wave * G::MT1 + i) + l15;     // this lane's halo pixel
+        if (hp < G::HP) {
+          float m = 1.f;
+          if (border) {
+            const int hy = hp / G::IW, hx = hp - hy * G::IW;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            m = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? 1.f : 0.f;
+          }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int hp = 16 * (wave * G::MT1 + i) + 4 * q + r;
-          if (hp < G::HP) {
-            float m = 1.f;
-            if (border) {
-              const int hy = hp / G::IW, hx = hp - hy * G::IW;
-              const int iy = iy0 + hy, ix = ix0 + hx;
-              m = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? 1.f : 0.f;
-            }
-#pragma unroll
-            for (int n = 0; n < G::NT1; ++n) sE[hp * CC + 16 * n + l15] = m * lrelu_max(acc[i][n][r]);
+          for (int n = 0; n < G::NT1; ++n) {
+            f32x4 v = acc[i][n];
+            v.x = m * lrelu_max(v.x); v.y = m * lrelu_max(v.y); v.z = m * lrelu_max(v.z); v.w = m * lrelu_max(v.w);
+            *reinterpret_cast<f32x4*>(sE + hp * CC + 16 * n + 4 * q) = v;
           }
         }
+      }
     }
     __syncthreads();  // E complete; every wave is done with the previous chunk's P3
     if (ch + 1 < NCH) {
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
 #pragma unroll
           for (int i = 0; i < G::MT3; ++i)
 #pragma unroll
-            for (int n = 0; n < G::NT3; ++n) acc3[i][n] = mfma16(fa[i][s], fb[n][s], acc3[i][n]);
+            for (int n = 0; n < G::NT3; ++n) acc3[i][n] = mfma16(fb[n][s], fa[i][s], acc3[i][n]);   // D[cout][pixel]
       }
     }
     // no barrier here: the next P1 writes E only, which nobody reads until after its barrier
@@ -338,14 +343,14 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
     if (n0) __syncthreads();  // previous slice fully stored before it is overwritten
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
-      const float bias = b2[16 * (n0 + nn) + l15];
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(b2 + 16 * (n0 + nn) + 4 * q);
 #pragma unroll
-      for (int i = 0; i < G::MT3; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int p = 16 * (wave * G::MT3 + i) + 4 * q + r;
-          sO[p * G::LDO + 16 * nn + l15] = lrelu_max(acc3[i][n0 + nn][r] + bias);
-        }
+      for (int i = 0; i < G::MT3; ++i) {
+        const int p = 16 * (wave * G::MT3 + i) + l15;      // acc3 rows = 4 consecutive output channels
+        f32x4 v = acc3[i][n0 + nn] + bias;
+        v.x = lrelu_max(v.x); v.y = lrelu_max(v.y); v.z = lrelu_max(v.z); v.w = lrelu_max(v.w);
+        *reinterpret_cast<f32x4*>(sO + p * G::LDO + 16 * nn + 4 * q) = v;
+      }
     }
     __syncthreads();
     for (int idx = tid; idx < G::OP * 8; idx += 256) {
