@@ -130,6 +130,8 @@ int launch_cross_attention(const void* q, int ldq, const void* k, int ldk, const
                            int ld_out, int batch, hipStream_t stream, int dtype = DT_F32);
 int launch_nchw_to_nhwc(const float* in, void* out, int batch, int c, int hw, hipStream_t stream,
                         int dtype = DT_F32);
+int launch_crop_to_input(const unsigned char* crops, float* x, int batch, hipStream_t stream);
+int launch_pred_to_u8(const float* pred, unsigned char* out, int batch, hipStream_t stream);
 int launch_audio_window_gather(const float* features, int n_steps, const int* idx_dev, void* out, int batch,
                                hipStream_t stream, int dtype = DT_F32);
 int launch_inc(const float* x_nchw, const float* packed_inc, void* out, int ldc, int batch,

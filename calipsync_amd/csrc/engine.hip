@@ -812,6 +812,12 @@ int casync_op_inc(const float* x_nchw, const float* packed_inc, void* out, int l
                   casync_stream stream) {
   return launch_inc(x_nchw, packed_inc, out, ldc, batch, (hipStream_t)stream, g_op_dtype);
 }
+int casync_op_crop_to_input(const uint8_t* crops168_dev, float* x_dev, int batch, casync_stream stream) {
+  return launch_crop_to_input(crops168_dev, x_dev, batch, (hipStream_t)stream);
+}
+int casync_op_pred_to_u8(const float* pred_dev, uint8_t* out_dev, int batch, casync_stream stream) {
+  return launch_pred_to_u8(pred_dev, out_dev, batch, (hipStream_t)stream);
+}
 int casync_op_outc(const void* in, int ld_in, const float* w, const float* b, float* out_nchw,
                    int batch, casync_stream stream) {
   return launch_outc(in, ld_in, w, b, out_nchw, batch, (hipStream_t)stream, g_op_dtype);

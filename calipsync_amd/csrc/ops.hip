@@ -189,6 +189,41 @@ __global__ __launch_bounds__(256) void audio_window_gather_kernel(const float* _
   st4(out + ((size_t)b * 1024 + p) * 32 + c, v);
 }
 
+// ---------------------------------------------------------------- frame-loop tensor glue
+// FrameSynthesizer.process_batch around the model call (infer_api.py:238-245 and 265-266):
+//   pre : crop168 (uint8 HWC BGR) -> inner [4:164,4:164]; masked copy = same with the filled black
+//         rectangle (x,y,w,h) = (5,5,150,145), i.e. x in [5,154], y in [5,149]; both HWC->CHW, /255
+//         (fp32 division), concat -> x[6,160,160]
+//   post: pred[3,160,160] * 255 -> uint8 (truncation) -> HWC
+// Pure indexing + one IEEE op each, so the kernels are bit-exact against the numpy restatement.
+__global__ __launch_bounds__(256) void crop_to_input_kernel(const unsigned char* __restrict__ crops,
+                                                            float* __restrict__ x, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // one output pixel (all 6 channels)
+  if (i >= total) return;
+  const int px = (int)(i % 160), py = (int)((i / 160) % 160);
+  const long long b = i / 25600;
+  const unsigned char* src = crops + ((b * 168 + py + 4) * 168 + px + 4) * 3;
+  const bool masked = px >= 5 && px < 155 && py >= 5 && py < 150;
+  float* dst = x + b * 6 * 25600 + py * 160 + px;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = (float)src[c] / 255.0f;
+    dst[c * 25600] = v;
+    dst[(3 + c) * 25600] = masked ? 0.f : v;
+  }
+}
+
+__global__ __launch_bounds__(256) void pred_to_u8_kernel(const float* __restrict__ pred,
+                                                         unsigned char* __restrict__ out, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // one pixel
+  if (i >= total) return;
+  const long long b = i / 25600, p = i - b * 25600;
+  const float* src = pred + b * 3 * 25600 + p;
+  unsigned char* dst = out + i * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) dst[c] = (unsigned char)(src[c * 25600] * 255.0f);
+}
+
 // ---------------------------------------------------------------- inc (6 -> 12 -> dw -> 32)
 // Block = 8 rows x 32 columns of one frame.  Phase A: 1x1 expand (+bias, LReLU) of the
 // 10 x 34 halo into LDS, zero where the halo leaves the image (the depthwise conv pads the
@@ -369,6 +404,22 @@ int launch_nchw_to_nhwc(const float* in, void* out, int batch, int c, int hw, hi
                                  (float*)out, c, hw, total),
               hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(blocks_for(total)), dim3(256), 0, stream, in,
                                  (bf16_t*)out, c, hw, total));
+  CASYNC_CHECK_HIP(hipGetLastError());
+  return CASYNC_OK;
+}
+
+int launch_crop_to_input(const unsigned char* crops, float* x, int batch, hipStream_t stream) {
+  CASYNC_REQUIRE(crops && x && batch > 0, "crop_to_input: bad args");
+  const long long total = (long long)batch * 25600;
+  hipLaunchKernelGGL(crop_to_input_kernel, dim3(blocks_for(total)), dim3(256), 0, stream, crops, x, total);
+  CASYNC_CHECK_HIP(hipGetLastError());
+  return CASYNC_OK;
+}
+
+int launch_pred_to_u8(const float* pred, unsigned char* out, int batch, hipStream_t stream) {
+  CASYNC_REQUIRE(pred && out && batch > 0, "pred_to_u8: bad args");
+  const long long total = (long long)batch * 25600;
+  hipLaunchKernelGGL(pred_to_u8_kernel, dim3(blocks_for(total)), dim3(256), 0, stream, pred, out, total);
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }

@@ -164,6 +164,13 @@ int casync_op_cross_attention(const void* q, int ldq, const void* k, int ldk,
                               const void* v, int ldv, const void* res, int ld_res,
                               const float* gamma_dev, void* out, int ld_out,
                               int batch, casync_stream stream);
+/* Tensor glue of FrameSynthesizer.process_batch around the model call, on the device:
+ * crop_to_input: resized 168x168 BGR crops (uint8 HWC) -> the [B,6,160,160] fp32 model input
+ *   (inner [4:164,4:164], masked copy with the black rectangle (5,5,150,145), HWC->CHW, /255,
+ *   concat) -- infer_api.py:238-245;  pred_to_u8: pred*255 -> uint8 HWC [B,160,160,3]
+ *   (truncation) -- infer_api.py:265-266.  Bit-exact; cv2.resize / blending stay on the host. */
+int casync_op_crop_to_input(const uint8_t* crops168_dev, float* x_dev, int batch, casync_stream stream);
+int casync_op_pred_to_u8(const float* pred_dev, uint8_t* out_dev, int batch, casync_stream stream);
 /* NCHW <-> NHWC helpers */
 int casync_op_nchw_to_nhwc(const float* in, void* out, int batch, int c, int hw,
                            casync_stream stream);

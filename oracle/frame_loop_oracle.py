@@ -31,3 +31,23 @@ def get_audio_features(features: np.ndarray, indices) -> np.ndarray:
         if win.size >= 32 * 32 * 32:                    # :131-135
             out[k] = win.reshape(32, 32, 32)
     return out
+
+
+def crops_to_model_input(crops168: np.ndarray) -> np.ndarray:
+    """[B,168,168,3] uint8 -> [B,6,160,160] fp32 (infer_api.py:238-245).
+
+    ``cv2.rectangle(img, (5, 5, 150, 145), (0,0,0), -1)`` fills the rectangle x,y,w,h = 5,5,150,145:
+    columns 5..154, rows 5..149 (restated with slicing; cv2 is absent here)."""
+    out = np.empty((crops168.shape[0], 6, 160, 160), dtype=np.float32)
+    for b, crop in enumerate(crops168):
+        real = crop[4:164, 4:164].copy()                       # :238
+        masked = real.copy()                                   # :239
+        masked[5:150, 5:155] = 0
+        out[b, :3] = real.transpose(2, 0, 1).astype(np.float32) / 255.0      # :241
+        out[b, 3:] = masked.transpose(2, 0, 1).astype(np.float32) / 255.0    # :242
+    return out
+
+
+def predictions_to_uint8(pred: np.ndarray) -> np.ndarray:
+    """[B,3,160,160] fp32 -> [B,160,160,3] uint8 (infer_api.py:265-266)."""
+    return np.stack([np.array(p.transpose(1, 2, 0) * 255, dtype=np.uint8) for p in pred])

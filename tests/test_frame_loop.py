@@ -45,3 +45,27 @@ def test_device_window_gather_matches_host_windows(recipe_sd, precision):
     got = net.forward_windows(xt, torch.from_numpy(feats).cuda(), idx)
     assert torch.equal(got, ref)
     assert (net(xt, host.flip(0).contiguous()) - ref).abs().max() > 1e-3   # the windows matter
+
+
+def test_crop_oracle_layout():
+    crops = np.random.default_rng(0).integers(0, 256, (2, 168, 168, 3), dtype=np.uint8)
+    x = frame_loop_oracle.crops_to_model_input(crops)
+    assert x.shape == (2, 6, 160, 160) and x.dtype == np.float32
+    assert x[1, 2, 0, 0] == np.float32(crops[1, 4, 4, 2]) / np.float32(255.0)
+    assert not x[:, 3:, 5:150, 5:155].any()                       # the blacked-out mouth rectangle
+    assert np.array_equal(x[:, 3:, :5], x[:, :3, :5]) and np.array_equal(x[:, 3:, :, 155:], x[:, :3, :, 155:])
+
+
+@pytest.mark.gpu
+def test_device_crop_and_u8_are_bit_exact():
+    from calipsync_amd import frame_loop
+    rng = np.random.default_rng(1)
+    crops = rng.integers(0, 256, (5, 168, 168, 3), dtype=np.uint8)
+    x = frame_loop.crops_to_model_input(torch.from_numpy(crops).cuda())
+    assert torch.equal(x.cpu(), torch.from_numpy(frame_loop_oracle.crops_to_model_input(crops)))
+    pred = rng.random((5, 3, 160, 160), dtype=np.float32)
+    pred[0, 0, 0, :4] = [0.0, 0.999999, 1.0 / 255, 0.5]            # truncation edge values
+    u8 = frame_loop.predictions_to_uint8(torch.from_numpy(pred).cuda())
+    assert torch.equal(u8.cpu(), torch.from_numpy(frame_loop_oracle.predictions_to_uint8(pred)))
+    with pytest.raises(RuntimeError):
+        frame_loop.crops_to_model_input(torch.from_numpy(crops))    # CPU tensor: no fallback
