@@ -625,6 +625,10 @@ static int ensure_streams(casync_handle h) {
   return CASYNC_OK;
 }
 
+// Lanes pay off once each half-batch still fills the chip (measured: B=8 -16 %, B=16 +-0, B=32 +7 %,
+// B=64 +4 % with two lanes; tools/latency_sweep.py).
+constexpr int kMinLaneBatch = 12;
+
 static int forward_impl(casync_handle h, const float* x, const float* a, const float* feat, int n_steps,
                         const int* idx, float* out, int batch, void* ws, int64_t ws_bytes,
                         casync_stream stream);
@@ -651,7 +655,7 @@ static int forward_impl(casync_handle h, const float* x, const float* a, const f
   const bool overlap = env_int("CASYNC_OVERLAP", 1) != 0;
   int lanes = env_int("CASYNC_LANES", 2);
   lanes = lanes < 1 ? 1 : (lanes > casync_engine::kMaxLanes ? casync_engine::kMaxLanes : lanes);
-  if (batch < 2 * lanes) lanes = 1;  // tiny batches: not worth cutting
+  if (batch < kMinLaneBatch * lanes) lanes = 1;  // small batches are latency-bound: cutting them only adds launches
   if (overlap || lanes > 1) {
     st = ensure_streams(h);
     if (st != CASYNC_OK) return st;
@@ -696,7 +700,7 @@ int casync_profile_forward(casync_handle h, const float* x, const float* a, floa
   // casync_forward, but serialised on the caller's stream with an event pair around each.
   int lanes = env_int("CASYNC_LANES", 2);
   lanes = lanes < 1 ? 1 : (lanes > casync_engine::kMaxLanes ? casync_engine::kMaxLanes : lanes);
-  if (batch < 2 * lanes) lanes = 1;
+  if (batch < kMinLaneBatch * lanes) lanes = 1;
   int n = 0, b0 = 0;
   for (int l = 0; l < lanes; ++l) {
     const int bl = batch / lanes + (l < batch % lanes ? 1 : 0);

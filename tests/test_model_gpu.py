@@ -74,6 +74,20 @@ def test_frames_independent_and_batch_invariant(net):
     assert torch.equal(full[3:4], part)              # bitwise: same kernels, same order per frame
 
 
+def test_lanes_and_stream_overlap_do_not_change_bits(net, monkeypatch):
+    """The batch is cut into concurrent lanes (ragged: 37 = 19 + 18 = 13 + 12 + 12) and the audio
+    branch runs on a side stream; both are scheduling only, so the output must be bit-identical."""
+    x, a = recipe.make_inputs(37)
+    xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
+    monkeypatch.setenv("CASYNC_LANES", "1")
+    monkeypatch.setenv("CASYNC_OVERLAP", "0")
+    base = net(xt, at)
+    for lanes, overlap in (("1", "1"), ("2", "1"), ("3", "1"), ("2", "0")):
+        monkeypatch.setenv("CASYNC_LANES", lanes)
+        monkeypatch.setenv("CASYNC_OVERLAP", overlap)
+        assert torch.equal(net(xt, at), base), (lanes, overlap)
+
+
 def test_audio_matters(net):
     x, a = recipe.make_inputs(2)
     xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
