@@ -169,6 +169,8 @@ def main():
         # per-kernel durations there are not separable.  The roofline pass therefore replays the
         # SAME batch with the launches isolated: one lane, one stream, an event pair per launch.
         os.environ["CASYNC_LANES"] = "1"
+        if lanes > 1:
+            os.environ["CASYNC_GEMM_STREAMK"] = "0"     # the timed multi-lane run uses plain tiles: replay those
         for _ in range(reps):
             for row in net.profile(x, a):
                 c = per.setdefault(row["kernel"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})

@@ -99,9 +99,17 @@ struct GemmEpilogue {
   const void* acc_in = nullptr;      // (T) running sum: acc_out = acc_in + v
   void* acc_out = nullptr;           // (T)
   int ld_acc = 0;
+  // stream-K scratch (null = plain data-parallel tiles): kStreamKFloats floats of partial tiles and
+  // kStreamKCounters zeroed counters, private to the stream the GEMM runs on
+  float* sk_ws = nullptr;
+  unsigned* sk_cnt = nullptr;
 };
+constexpr int kStreamKWgs = 256;                                  // stream-K workgroups (one per CU)
+constexpr long long kStreamKFloats = 2ll * kStreamKWgs * 128 * 64;  // two partial tiles per workgroup, up to 128x64
+constexpr int kStreamKCounters = 256;
+constexpr long long kStreamKBytes = kStreamKFloats * 4 + kStreamKCounters * 4;
 
-const char* pw_gemm_kernel_name(int m, int n, int dtype = DT_F32);
+const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype = DT_F32);
 // a, w, c (and the (T) epilogue pointers) are `dtype` elements; lda/ldc in elements
 int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int m, int n, int k,
                    const GemmEpilogue& epi, hipStream_t stream, int dtype = DT_F32);

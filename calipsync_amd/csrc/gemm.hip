@@ -223,6 +223,34 @@ __global__ __launch_bounds__(64 * WM * WN) void pw_gemm_kernel(const T* __restri
   }
 }
 
+// Stream-K split of a launch of `tiles` output tiles with `nk` k-iterations each (ring kernel).
+// Whole rounds of 256 tiles stay data-parallel; the remainder's iterations are cut into equal runs,
+// one per CU, so the last round costs remainder/256 of a tile time instead of a whole one
+// (M = 6400 rows leave 78-89 % of a round empty otherwise; measured 83 -> 105 TFLOP/s class).
+struct StreamKSplit { long long dp_tiles; int wgs, per; };
+inline int stream_k_mode() {   // read per launch: CASYNC_GEMM_STREAMK=0 gives batch-invariant bits (tests)
+  const char* e = getenv("CASYNC_GEMM_STREAMK");
+  return e && *e ? atoi(e) : 1;
+}
+inline StreamKSplit stream_k_split(long long tiles, int nk, int tile_floats, bool have_scratch) {
+  StreamKSplit s{tiles, 0, 0};
+  const long long rem = tiles % kStreamKWgs;
+  if (rem > 224) return s;   // a nearly full last round: the fix-up would cost more than it saves
+  // needs scratch, a remainder worth balancing, tiles that fit the scratch slots and enough
+  // k-iterations per run to keep the ring busy
+  if (!have_scratch || !stream_k_mode() || rem == 0 || nk < 8 ||
+      (long long)tile_floats * 2 * kStreamKWgs > kStreamKFloats)
+    return s;
+  const long long its = rem * nk;
+  long long wgs = its / 4 < kStreamKWgs ? its / 4 : kStreamKWgs;   // >= 4 iterations per run
+  if (wgs < rem) wgs = rem;                                        // per <= nk: at most two tiles per run
+  if (wgs <= rem) return s;                                        // nothing to split
+  s.dp_tiles = tiles - rem;
+  s.per = (int)((its + wgs - 1) / wgs);
+  s.wgs = (int)((its + s.per - 1) / s.per);
+  return s;
+}
+
 // =====================================================================================
 // Direct-to-LDS variant: the k-tiles arrive by global_load_lds_dwordx4 (no register staging, no
 // ds_write) into an NST-deep ring, NST-1 tiles ahead of the MFMAs.  A bf16 k-tile is only ~512 MFMA
@@ -242,7 +270,8 @@ template <typename T, int BM, int BN, int WM, int WN, int NST>
 __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__ A, int lda,
                                                            const T* __restrict__ W, T* __restrict__ C,
                                                            int ldc, int M, int N, int K, int n_ntiles,
-                                                           int nwg, GemmEpilogue epi) {
+                                                           int nwg, int dp_tiles, int sk_wgs, int sk_per,
+                                                           GemmEpilogue epi) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int BK = ROWB / (int)sizeof(T);
   constexpr int E16 = 16 / (int)sizeof(T);
@@ -267,16 +296,27 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
   const int c4 = (tid % TPR) * 4, rr = tid / TPR;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
 
-  for (int tile = blockIdx.x; tile < nwg; tile += gridDim.x) {
-    int m0, n0;
-    {
-      const int q = nwg >> 3, r = nwg & 7, xcd = tile & 7, idx = tile >> 3;
-      const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-      const int mt = bid / n_ntiles;
-      m0 = mt * BM;
-      n0 = (bid - mt * n_ntiles) * BN;
-    }
-    // this lane's source pointer for each of the wave's LPT instructions (k-tile 0)
+  f32x16 acc[TM][TN];
+  int m0 = 0, n0 = 0;
+  auto tile_origin = [&](int tile) {   // XCD-aware bijection tile -> (m0, n0)
+    const int q = nwg >> 3, r = nwg & 7, xcd = tile & 7, idx = tile >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int mt = bid / n_ntiles;
+    m0 = mt * BM;
+    n0 = (bid - mt * n_ntiles) * BN;
+  };
+  auto zero_acc = [&] {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+
+  // acc = A[m0.., k-tiles k0 .. k0+cnt) . W[n0.., same k-tiles)^T; ends with the ring idle
+  auto run_k = [&](int k0, int cnt) {
+    // this lane's source pointer for each of the wave's LPT instructions (k-tile k0)
     const T* src[LPT];
 #pragma unroll
     for (int j = 0; j < LPT; ++j) {
@@ -285,9 +325,9 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
       if (r < BM) {
         int row = m0 + r;
         row = row < M ? row : M - 1;
-        src[j] = A + (size_t)row * lda + cs * E16;
+        src[j] = A + (size_t)row * lda + cs * E16 + (size_t)k0 * BK;
       } else {
-        src[j] = W + (size_t)(n0 + r - BM) * K + cs * E16;
+        src[j] = W + (size_t)(n0 + r - BM) * K + cs * E16 + (size_t)k0 * BK;
       }
     }
     auto issue = [&](int kt) {
@@ -298,18 +338,10 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
             (const void __attribute__((address_space(1)))*)(src[j] + (size_t)kt * BK),
             (void __attribute__((address_space(3)))*)(st + (j * 4 + wave) * 8 * ROWB), 16, 0, 0);
     };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
+    zero_acc();
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
-      if (s < nk) issue(s);
+      if (s < cnt) issue(s);
 
     // fragment addressing: row byte offset and swizzle key are loop-invariant per lane
     int a_off[TM], a_key[TM], b_off[TN], b_key[TN];
@@ -326,15 +358,15 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
       b_key[j] = (r >> 1) & 7;
     }
 
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt < cnt; ++kt) {
       // tiles kt+1 .. kt+NST-2 may stay in flight (fewer near the end of the k loop)
-      const int ahead = nk - 1 - kt;
+      const int ahead = cnt - 1 - kt;
       if (NST >= 4 && ahead >= 2) wait_vmcnt<(NST >= 4 ? 2 : 0) * LPT>();
       else if (NST >= 3 && ahead >= 1) wait_vmcnt<LPT>();
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (kt + NST - 1 < nk) issue(kt + NST - 1);
+      if (kt + NST - 1 < cnt) issue(kt + NST - 1);
       const char* st = ring + (kt % NST) * STAGE;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -351,8 +383,11 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
           for (int j = 0; j < TN; ++j) acc[i][j] = MfmaK<T>::run(fa[i], fb[j], acc[i][j]);
       }
     }
-    __syncthreads();   // everything landed and consumed: the ring becomes the C tile
+    __syncthreads();   // everything landed and consumed: the ring is free (it becomes the C tile)
+  };
 
+  // acc -> C tile in LDS -> bias / residuals / activation -> coalesced store; ends with the ring idle
+  auto epilogue = [&] {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -390,7 +425,79 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
         st4(static_cast<T*>(epi.acc_out) + (size_t)m * epi.ld_acc + n, s);
       }
     }
-    __syncthreads();   // C tile consumed before the next tile's loads overwrite the ring
+    __syncthreads();   // C tile consumed before the next loads overwrite the ring
+  };
+
+  // ---- stream-K part: the k-iterations of the remaining tiles, cut into sk_wgs equal runs of
+  //      sk_per (<= nk, so a run touches at most two tiles).  A run that does not cover its tile
+  //      parks the partial accumulators in the scratch, adds its iteration count to the tile's
+  //      counter, and the run that completes the count sums the partials IN RUN ORDER (the result
+  //      does not depend on arrival order) and applies the epilogue.  Nobody waits on anybody.
+  //      The runs go to the LAST workgroups of the grid (the ones with the fewest whole tiles) and
+  //      are done BEFORE the whole tiles, so the parking / fix-up latency hides under the
+  //      data-parallel work of the co-resident workgroups instead of forming the tail.
+  const int g = (int)gridDim.x - 1 - (int)blockIdx.x;
+  if (g < sk_wgs) {
+  const long long it_total = (long long)(nwg - dp_tiles) * nk;
+  long long it = (long long)g * sk_per;
+  const long long it_end = it + sk_per < it_total ? it + sk_per : it_total;
+  constexpr int SLOT = BM * BN;   // floats per parked tile = TM*TN*16 per thread
+  for (int seg = 0; it < it_end; ++seg) {
+    const int t = (int)(it / nk);
+    const int k0 = (int)(it - (long long)t * nk);
+    const int cnt = (int)((long long)(nk - k0) < it_end - it ? (long long)(nk - k0) : it_end - it);
+    it += cnt;
+    tile_origin(dp_tiles + t);
+    run_k(k0, cnt);
+    if (cnt != nk) {
+      float* slot = epi.sk_ws + (size_t)(2 * g + seg) * SLOT + tid;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            __hip_atomic_store(slot + ((i * TN + j) * 16 + r) * 256, acc[i][j][r], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+      // The eight XCDs have private L2s.  A device-scope fence would write back and invalidate the
+      // whole L2 (measured: +65 us per launch); instead the parked words themselves are agent-scope
+      // accesses (write-through stores, L2-bypassing loads) ordered by vmcnt(0) + the barrier in
+      // front of the counter update.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int* flag = reinterpret_cast<int*>(ring);
+      if (tid == 0)
+        *flag = __hip_atomic_fetch_add(epi.sk_cnt + t, (unsigned)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                    (unsigned)cnt == (unsigned)nk;
+      __syncthreads();
+      const bool last = *flag != 0;
+      __syncthreads();   // the flag word is ring memory: read before anything is loaded over it
+      if (!last) continue;
+      const int g0 = (int)(((long long)t * nk) / sk_per), g1 = (int)(((long long)t * nk + nk - 1) / sk_per);
+      zero_acc();
+      for (int gg = g0; gg <= g1; ++gg) {
+        const int sg = (int)(((long long)gg * sk_per) / nk) == t ? 0 : 1;   // t is run gg's first or second tile
+        const float* part = epi.sk_ws + (size_t)(2 * gg + sg) * SLOT + tid;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              acc[i][j][r] += __hip_atomic_load(part + ((i * TN + j) * 16 + r) * 256, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (tid == 0) __hip_atomic_store(epi.sk_cnt + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zeroed for the next launch
+    }
+    epilogue();
+  }
+  }
+
+  // ---- data-parallel part: whole tiles, every workgroup strides over them ----
+  for (int tile = blockIdx.x; tile < dp_tiles; tile += gridDim.x) {
+    tile_origin(tile);
+    run_k(0, nk);
+    epilogue();
   }
 }
 
@@ -410,9 +517,11 @@ int launch_glds_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, 
   CASYNC_REQUIRE(nwg < (1ll << 31), "gemm grid too large");
   constexpr int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
   const long long cap = 256ll * per_cu;
-  const unsigned grid = (unsigned)(nwg > cap ? cap : nwg);
+  const StreamKSplit sk = stream_k_split(nwg, k / (ROWB / (int)sizeof(T)), BM * BN, epi.sk_ws != nullptr);
+  const long long want = sk.dp_tiles + sk.wgs;
+  const unsigned grid = (unsigned)(want > cap ? cap : want);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a, lda, w, c, ldc, m, n, k, n_ntiles,
-                     (int)nwg, epi);
+                     (int)nwg, (int)sk.dp_tiles, sk.wgs, sk.per, epi);
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }
@@ -481,20 +590,37 @@ int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, i
 // pick the tile that minimises rounds x tile area, preferring the larger tile on ties.
 enum Cfg { C128x128 = 0, C128x64, C64x64, C128x32, C64x32, C64x64W2, CFG_COUNT };
 
-int pick_cfg(int m, int n) {
+struct TileCfg { Cfg id; int bm, bn; };
+constexpr TileCfg kTiles[] = {{C128x128, 128, 128}, {C128x64, 128, 64}, {C64x64, 64, 64}, {C128x32, 128, 32},
+                              {C64x32, 64, 32}, {C64x64W2, 64, 64}};
+
+// does launch_cfg() send this config to the LDS-DMA ring kernel?
+bool takes_ring(const TileCfg& t, long long tiles, int dtype) {
+  return (t.id == C128x128 || t.id == C128x64 || t.id == C64x64) && (t.bm + t.bn < 256 || tiles <= 256) &&
+         ((dtype == DT_BF16 && glds_mode() >= 1) || (dtype == DT_F32 && glds_mode() >= 2));
+}
+
+int pick_cfg(int m, int n, int k, bool stream_k, int dtype) {
   static const int forced = [] { const char* v = getenv("CASYNC_GEMM_CFG"); return v ? atoi(v) : -1; }();
-  struct T { Cfg id; int bm, bn; };
-  const T tiles[] = {{C128x128, 128, 128}, {C128x64, 128, 64}, {C64x64, 64, 64}, {C128x32, 128, 32},
-                     {C64x32, 64, 32}, {C64x64W2, 64, 64}};
-  if (forced >= 0 && forced < CFG_COUNT && n % tiles[forced].bn == 0) return forced;
+  if (forced >= 0 && forced < CFG_COUNT && n % kTiles[forced].bn == 0) return forced;
+  // Cost model fitted to tools/experiments/streamk_sweep.sh: a launch costs a fixed ~17 us (not
+  // modelled, equal for all) plus rounds x nk x (area + 600) / 8192 us, where a "round" is one
+  // tile per CU (co-resident tiles share the CU's matrix pipes, so they add, not overlap) and the
+  // +600 is the worse operand reuse of small tiles.  Stream-K makes the last round fractional
+  // and adds ~5 us (64x64) to ~10 us (128x64) of short-run start-up, parking and fix-up (priced
+  // a little higher here so that it is only chosen where it clearly wins).
   int best = -1;
   double best_cost = 0;
-  for (const T& t : tiles) {
+  const int nk = k / (ROWB / dtype_size(dtype));
+  for (const TileCfg& t : kTiles) {
     if (n % t.bn || t.id >= C64x32) continue;   // experimental configs: only when forced
     const long long g = (long long)((m + t.bm - 1) / t.bm) * (n / t.bn);
-    const double rounds = (double)((g + 255) / 256);
-    // small per-round overhead so that, when rounds x area ties, fewer / larger tiles win
-    const double cost = rounds * (t.bm * t.bn + 600.0);
+    double rounds = (double)((g + 255) / 256), extra = 0.0;
+    if (takes_ring(t, g, dtype)) {
+      const StreamKSplit sk = stream_k_split(g, nk, t.bm * t.bn, stream_k);
+      if (sk.wgs) rounds = (double)g / 256.0, extra = 2.5 + 9.5 * (t.bm * t.bn) / 8192.0;
+    }
+    const double cost = rounds * nk * (t.bm * t.bn + 600.0) / 8192.0 + extra;
     if (best < 0 || cost < best_cost) best = t.id, best_cost = cost;
   }
   return best;
@@ -503,11 +629,12 @@ int pick_cfg(int m, int n) {
 }  // namespace
 
 // Name of the kernel instance launch_pw_gemm() will pick (as rocprofv3 prints it).
-const char* pw_gemm_kernel_name(int m, int n, int dtype) {
+const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype) {
   static thread_local char buf[64];
   const char* t = dtype == DT_BF16 ? "__bf16" : "float";
+  const int id = pick_cfg(m, n, k, stream_k, dtype);
   const char* cfg;
-  switch (pick_cfg(m, n)) {
+  switch (id) {
     case C128x128: cfg = "128, 128, 2, 2"; break;
     case C128x64: cfg = "128, 64, 2, 2"; break;
     case C64x64: cfg = "64, 64, 2, 2"; break;
@@ -515,14 +642,11 @@ const char* pw_gemm_kernel_name(int m, int n, int dtype) {
     case C64x64W2: cfg = "64, 64, 2, 1"; break;
     default: cfg = "128, 32, 4, 1"; break;
   }
-  const int id = pick_cfg(m, n);
-  const int bm = (id == C64x64 || id == C64x32 || id == C64x64W2) ? 64 : 128;
-  const int bn = id == C128x128 ? 128 : (id == C128x64 || id == C64x64 || id == C64x64W2 ? 64 : 32);
-  const long long tiles = (long long)((m + bm - 1) / bm) * (n / bn);
-  const bool ring = (id == C128x128 || id == C128x64 || id == C64x64) && (bm + bn < 256 || tiles <= 256) &&
-                    ((dtype == DT_BF16 && glds_mode() >= 1) || (dtype == DT_F32 && glds_mode() >= 2));
-  if (ring)
-    snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, %d>", t, cfg, bm + bn >= 256 ? 3 : (bm + bn >= 192 ? 2 : 3));
+  const TileCfg& tc = kTiles[id];
+  const long long tiles = (long long)((m + tc.bm - 1) / tc.bm) * (n / tc.bn);
+  if (takes_ring(tc, tiles, dtype))
+    snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, %d>", t, cfg,
+             tc.bm + tc.bn >= 256 ? 3 : (tc.bm + tc.bn >= 192 ? 2 : 3));
   else
     snprintf(buf, sizeof(buf), "pw_gemm_kernel<%s, %s>", t, cfg);
   return buf;
@@ -544,7 +668,7 @@ int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int 
   CASYNC_REQUIRE((!epi.pre_res || epi.ld_pre % 4 == 0) && (!epi.post_res || epi.ld_post % 4 == 0) &&
                      (!epi.acc_out || epi.ld_acc % 4 == 0),
                  "pw_gemm: residual leading dimensions must be multiples of 4");
-  switch (pick_cfg(m, n)) {
+  switch (pick_cfg(m, n, k, epi.sk_ws != nullptr, dtype)) {
     case C128x128: return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype);
     case C128x64: return launch_cfg<128, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype);
     case C64x64: return launch_cfg<64, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype);

@@ -65,20 +65,29 @@ def test_against_oracle(net, recipe_sd, batch):
     assert d < TOL and d < EXPECT
 
 
-def test_frames_independent_and_batch_invariant(net):
+def test_frames_independent_and_batch_invariant(net, monkeypatch):
     """A frame's output must not depend on its neighbours or its position in the batch."""
     x, a = recipe.make_inputs(5)
     xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
     full = net(xt, at)
     part = net(xt[3:4].contiguous(), at[3:4].contiguous())
-    assert torch.equal(full[3:4], part)              # bitwise: same kernels, same order per frame
+    # stream-K splits a GEMM's k range differently for different row counts: fp32 reassociation only
+    assert (full[3:4] - part).abs().max() < 1e-5
+    assert torch.equal(net(xt, at), full)            # and it is repeatable bit for bit
+    monkeypatch.setenv("CASYNC_GEMM_STREAMK", "0")   # plain tiles: same order per frame -> bitwise
+    assert torch.equal(net(xt, at)[3:4], net(xt[3:4].contiguous(), at[3:4].contiguous()))
 
 
 def test_lanes_and_stream_overlap_do_not_change_bits(net, monkeypatch):
     """The batch is cut into concurrent lanes (ragged: 37 = 19 + 18 = 13 + 12 + 12) and the audio
-    branch runs on a side stream; both are scheduling only, so the output must be bit-identical."""
+    branch runs on a side stream; both are scheduling only, so with plain GEMM tiles the output is
+    bit-identical (with stream-K the k-split depends on the lane's row count: checked to 1e-5)."""
     x, a = recipe.make_inputs(37)
     xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
+    sk_full = net(xt, at)
+    monkeypatch.setenv("CASYNC_LANES", "1")
+    assert (net(xt, at) - sk_full).abs().max() < 1e-5
+    monkeypatch.setenv("CASYNC_GEMM_STREAMK", "0")
     monkeypatch.setenv("CASYNC_LANES", "1")
     monkeypatch.setenv("CASYNC_OVERLAP", "0")
     base = net(xt, at)
@@ -152,28 +161,39 @@ def test_bf16_intermediates_track_fp32(net_bf16, golden, name):
     assert rel < 6e-2
 
 
-def test_bf16_frames_independent(net_bf16):
+def test_bf16_frames_independent(net_bf16, monkeypatch):
     x, a = recipe.make_inputs(5)
     xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
     full = net_bf16(xt, at)
     part = net_bf16(xt[3:4].contiguous(), at[3:4].contiguous())
-    assert torch.equal(full[3:4], part)
+    assert (full[3:4] - part).abs().max() < 2e-2     # stream-K k-split differs with the row count: bf16 ulps
+    monkeypatch.setenv("CASYNC_GEMM_STREAMK", "0")
+    assert torch.equal(net_bf16(xt, at)[3:4], net_bf16(xt[3:4].contiguous(), at[3:4].contiguous()))
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_full_size_batch_properties(recipe_sd, precision):
+def test_full_size_batch_properties(recipe_sd, precision, monkeypatch):
     """BASELINE configs[2]/[3] per-GPU size (512 frames): no oracle run at this size; instead the
-    size-independent properties -- every frame equals its own single-frame forward bit for bit
-    (frames independent, lanes / tiling batch-invariant), duplicates agree, outputs in (0,1)."""
+    size-independent properties -- every frame equals its own single-frame forward (frames
+    independent, lanes / tiling batch-invariant: bit for bit with plain GEMM tiles, to rounding
+    with the stream-K k-split), duplicates agree, outputs in (0,1)."""
     m = Model(6, "hubert", precision=precision).to("cuda:0")
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe_sd.items()})
     x16, a16 = recipe.make_inputs(16)
     x = torch.from_numpy(x16).cuda().repeat(32, 1, 1, 1)          # 512 frames, 16 distinct
     a = torch.from_numpy(a16).cuda().repeat(32, 1, 1, 1)
+    tol = 1e-5 if precision == "fp32" else 2e-2
     out = m(x, a)
     assert out.shape == (512, 3, 160, 160) and torch.isfinite(out).all()
     assert out.min() > 0 and out.max() < 1
-    assert torch.equal(out[:16], out[256:272]) and torch.equal(out[5], out[16 * 31 + 5])   # duplicates, both lanes
+    assert torch.equal(out[:16], out[256:272])                    # same place in both lanes: same bits
+    assert (out[5] - out[16 * 31 + 5]).abs().max() < tol          # duplicates anywhere
+    for i in (0, 7, 15):
+        single = m(x[i:i + 1].contiguous(), a[i:i + 1].contiguous())
+        assert (single[0] - out[i]).abs().max() < tol, i
+    monkeypatch.setenv("CASYNC_GEMM_STREAMK", "0")
+    out = m(x, a)
+    assert torch.equal(out[:16], out[256:272]) and torch.equal(out[5], out[16 * 31 + 5])
     for i in (0, 7, 15):
         single = m(x[i:i + 1].contiguous(), a[i:i + 1].contiguous())
         assert torch.equal(single[0], out[i]), i

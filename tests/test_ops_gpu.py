@@ -35,6 +35,29 @@ def test_pw_gemm_plain(lib, m, n, k):
     assert rel_err(c.cpu(), ref) < 2e-6
 
 
+@pytest.mark.parametrize("m,n,k", [(6400, 512, 1024), (3200, 512, 512), (6400, 2304, 512), (3200, 1024, 2048),
+                                   (6400, 64, 512), (1111, 512, 256), (100, 512, 2304), (12800, 128, 1024)])
+def test_pw_gemm_stream_k_remainder(lib, m, n, k):
+    """Shapes whose tile count is not a multiple of 256: the remainder's k-iterations are split
+    over workgroups (stream-K) and recombined in a fixed order -> same accuracy, bit-repeatable,
+    counters left clean for the next launch (second and third launch identical)."""
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g)
+    pre = torch.randn(m, n, generator=g)
+    ref = F.leaky_relu(a.double() @ w.double().T + b.double() + pre.double(), 0.01).float()
+    ad, wd, bd, pd = a.to(dev()), w.to(dev()), b.to(dev()), pre.to(dev())
+    outs = []
+    for _ in range(3):
+        c = torch.full((m, n), float("nan"), device=dev())
+        ok(lib.casync_op_pw_gemm(ptr(ad), k, ptr(wd), ptr(bd), ptr(c), n, m, n, k, 1, ptr(pd), n, 0, 0, 0, 0, 0,
+                                 stream()))
+        outs.append(c.cpu())
+    assert rel_err(outs[0], ref) < 2e-6
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
 def test_pw_gemm_epilogue_and_strides(lib):
     """lda/ldc slices of wider buffers + pre-residual (scaled) + post-residual + affine."""
     g = torch.Generator().manual_seed(3)

@@ -78,10 +78,14 @@ def bench_gemm(args):
     s = torch.cuda.current_stream().cuda_stream
     tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     lib.casync_op_set_dtype(1 if args.dtype == "bf16" else 0)
-    for name, rows, n, k in GEMM_SHAPES:
+    shapes = GEMM_SHAPES
+    if args.shape:   # --shape M,N,K[;M,N,K...]: explicit sizes (M taken as is)
+        shapes = [("custom", int(v.split(",")[0]) / args.batch, int(v.split(",")[1]), int(v.split(",")[2]))
+                  for v in args.shape.split(";")]
+    for name, rows, n, k in shapes:
         if args.only and args.only not in name:
             continue
-        m = rows * args.batch
+        m = int(round(rows * args.batch))
         if k % (64 if args.dtype == "bf16" else 32):
             continue
         a = torch.randn(m, k, device=DEV).to(tdt)
@@ -104,6 +108,7 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--shape", default="")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     a = ap.parse_args()
     {"ir": bench_ir, "gemm": bench_gemm}[a.what](a)
