@@ -117,6 +117,7 @@ int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int 
 // ---- other operators -------------------------------------------------------
 int launch_dw3x3(const void* in, const float* w, const float* bias, void* out, int batch, int h,
                  int wdt, int c, int stride, hipStream_t stream, int dtype = DT_F32);
+const char* dw3x3_kernel_name(int h, int wdt, int c, int stride, int dtype = DT_F32);
 bool ir_fused_supported(int cin, int cout, int stride);
 const char* ir_fused_kernel_name(int cin, int cout, int stride, int dtype = DT_F32);
 bool ir_fused_up_supported(int cin, int cout);

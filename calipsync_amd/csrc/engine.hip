@@ -339,7 +339,7 @@ struct Plan {
     GemmEpilogue ep1;
     ep1.act = 1;
     gemm(p + ".pw1", in, ld_in, p + ".pw1.w", e1, b.cexp(), m_in, b.cexp(), b.cin, ep1);
-    r.run((p + ".dw").c_str(), kname("dw3x3_kernel", b.stride == 1 ? ", 1, 4" : ", 2, 2").c_str(),
+    r.run((p + ".dw").c_str(), dw3x3_kernel_name(b.hw_in, b.hw_in, b.cexp(), b.stride, dt()),
           2.0 * 9 * m_out * b.cexp(), dtype_size(dt()) * (double)(m_in + m_out) * b.cexp(), [&] {
       return launch_dw3x3(e1, e.W(p + ".dw.w"), e.W(p + ".dw.b"), e2, B, b.hw_in, b.hw_in, b.cexp(),
                           b.stride, r.s, dt());

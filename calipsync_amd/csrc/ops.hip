@@ -87,6 +87,71 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(const T* __restrict__ in,
   }
 }
 
+// Low-resolution variant (W <= 48, stride 1): the kernel above fetches every input ~4.5x through
+// L1 (3 tap rows x 1.5 column overlap), and at 10x10 .. 40x40 the vertical neighbours sit in other
+// workgroups, so it is L2-bandwidth-bound (~3 TB/s algorithmic).  Here a workgroup stages a
+// (TH+2) x (W+2) x CSV*16-B slab (zero borders included) in LDS with one coalesced pass -- every
+// input byte crosses L2 once (x (TH+2)/TH when the rows are tiled) -- and all nine taps read LDS.
+// One thread keeps one 16-B channel group (its tap weights stay in registers) and walks pixels.
+template <typename T, int CSV>
+__global__ __launch_bounds__(256) void dw3x3_lds_kernel(const T* __restrict__ in,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias,
+                                                        T* __restrict__ out, int H, int W, int C, int TH) {
+  constexpr int V = V16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) f32x4 dw_tile[];   // [(th+2)][W+2][CSV] raw 16-B chunks
+  const int tid = threadIdx.x;
+  const int c0 = blockIdx.x * CSV * V, y0 = blockIdx.y * TH, b = blockIdx.z;
+  const int th = TH < H - y0 ? TH : H - y0;
+  const int WP = W + 2;
+  const T* inb = in + (size_t)b * H * W * C + c0;
+  const int n_in = (th + 2) * WP * CSV;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < n_in; i += 256) {
+    const int cv = i % CSV, t = i / CSV;
+    const int r = t / WP, xc = t - r * WP;
+    const int iy = y0 - 1 + r, ix = xc - 1;
+    f32x4 v = zero;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+      v = *reinterpret_cast<const f32x4*>(inb + ((size_t)iy * W + ix) * C + cv * V);
+    dw_tile[i] = v;
+  }
+  // 256 % CSV == 0: a thread's channel group never changes
+  const int cv = tid % CSV, c = c0 + cv * V;
+  float wt[9][V], bv[V];
+#pragma unroll
+  for (int e = 0; e < V; e += 4) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(bias + c + e);
+    bv[e] = x[0]; bv[e + 1] = x[1]; bv[e + 2] = x[2]; bv[e + 3] = x[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const f32x4 y = *reinterpret_cast<const f32x4*>(w + k * C + c + e);
+      wt[k][e] = y[0]; wt[k][e + 1] = y[1]; wt[k][e + 2] = y[2]; wt[k][e + 3] = y[3];
+    }
+  }
+  __syncthreads();
+  T* outb = out + ((size_t)b * H + y0) * W * C + c;
+  const int n_out = th * W;
+  for (int p = tid / CSV; p < n_out; p += 256 / CSV) {
+    const int oy = p / W, ox = p - oy * W;
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = bv[e];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const V16<T> x = ld16(reinterpret_cast<const T*>(dw_tile + ((oy + ky) * WP + ox + kx) * CSV + cv));
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += x.v[e] * wt[ky * 3 + kx][e];
+      }
+    V16<T> r;
+#pragma unroll
+    for (int e = 0; e < V; ++e) r.v[e] = lrelu(acc[e]);
+    st16(outb + (size_t)p * C, r);
+  }
+}
+
 // ---------------------------------------------------------------- im2col (dense 3x3)
 template <typename T>
 __global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ in,
@@ -338,6 +403,39 @@ inline unsigned blocks_for(long long total) { return (unsigned)((total + 255) / 
     if ((dtype) == DT_BF16) { CALL_BF16; } else { CALL_F32; } \
   } while (0)
 
+// LDS-slab depthwise kernel for this shape?  Slab = 16 (narrow frames) or 8 16-B channel groups
+// wide, as many rows as keep it <= 64 KB, rows split evenly.
+static int lds_budget() {
+  static const int v = [] { const char* e = getenv("CASYNC_DW_LDS_BYTES"); return e && *e ? atoi(e) : 32768; }();
+  return v;
+}
+static bool dw_lds_plan(int h, int wdt, int c, int stride, int dtype, int* csv, int* th, int* nt) {
+  static const int enabled = [] { const char* e = getenv("CASYNC_DW_LDS"); return e && *e ? atoi(e) : 1; }();
+  if (!enabled || stride != 1 || wdt > 48) return false;
+  const int groups = c / (16 / dtype_size(dtype));
+  *csv = (wdt <= 12 && groups % 16 == 0) ? 16 : 8;   // 64-B slabs (half an L2 line per pixel) measured 25 % slower
+  // whole frames when they fit in 40 KB (no halo rows re-read), else <= 32 KB slabs: four or more
+  // workgroups per CU overlap one's load phase with another's tap phase (measured sweet spot)
+  const int whole = (h + 2) * (wdt + 2) * *csv * 16;
+  const int rows_max = (whole <= 40960 ? whole : lds_budget()) / ((wdt + 2) * *csv * 16) - 2;
+  if (groups % *csv || rows_max < 4) return false;
+  *th = h < rows_max ? h : rows_max;
+  *nt = (h + *th - 1) / *th;
+  *th = (h + *nt - 1) / *nt;
+  return true;
+}
+
+const char* dw3x3_kernel_name(int h, int wdt, int c, int stride, int dtype) {
+  static thread_local char buf[64];
+  const char* t = dtype == DT_BF16 ? "__bf16" : "float";
+  int csv, th, nt;
+  if (dw_lds_plan(h, wdt, c, stride, dtype, &csv, &th, &nt))
+    snprintf(buf, sizeof(buf), "dw3x3_lds_kernel<%s, %d>", t, csv);
+  else
+    snprintf(buf, sizeof(buf), "dw3x3_kernel<%s, %s>", t, stride == 1 ? "1, 4" : "2, 2");
+  return buf;
+}
+
 int launch_dw3x3(const void* in, const float* w, const float* bias, void* out, int batch, int h,
                  int wdt, int c, int stride, hipStream_t stream, int dtype) {
   CASYNC_REQUIRE(in && w && bias && out, "dw3x3: null pointer");
@@ -345,6 +443,21 @@ int launch_dw3x3(const void* in, const float* w, const float* bias, void* out, i
   CASYNC_REQUIRE(batch > 0 && h > 0 && wdt > 0 && c > 0 && c % vec == 0, "dw3x3: bad shape (C %% %d)", vec);
   CASYNC_REQUIRE(stride == 1 || stride == 2, "dw3x3: stride %d", stride);
   const int ho = (h + 2 - 3) / stride + 1, wo = (wdt + 2 - 3) / stride + 1;
+  {
+    int csv, th, nt;
+    if (dw_lds_plan(h, wdt, c, stride, dtype, &csv, &th, &nt)) {
+      const size_t lds = (size_t)(th + 2) * (wdt + 2) * csv * 16;
+      const dim3 grid(c / vec / csv, nt, batch);
+#define CASYNC_DW_LDS_LAUNCH(TT, CSVV)                                                                      \
+  hipLaunchKernelGGL((dw3x3_lds_kernel<TT, CSVV>), grid, dim3(256), lds, stream, (const TT*)in, w, bias, \
+                     (TT*)out, h, wdt, c, th)
+      if (csv == 16) DT_DISPATCH(dtype, CASYNC_DW_LDS_LAUNCH(float, 16), CASYNC_DW_LDS_LAUNCH(bf16_t, 16));
+      else DT_DISPATCH(dtype, CASYNC_DW_LDS_LAUNCH(float, 8), CASYNC_DW_LDS_LAUNCH(bf16_t, 8));
+#undef CASYNC_DW_LDS_LAUNCH
+      CASYNC_CHECK_HIP(hipGetLastError());
+      return CASYNC_OK;
+    }
+  }
   if (stride == 1) {
     constexpr int PX = 4;
     const int strips = (wo + PX - 1) / PX;

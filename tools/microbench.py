@@ -102,13 +102,36 @@ def bench_gemm(args):
         print(f"{name:12s} M={m:7d} N={n:5d} K={k:5d}  {ms:7.3f} ms  {2.0 * m * n * k / ms / 1e9:6.1f} TF  {gb:7.1f} GB/s", flush=True)
 
 
+DW_SHAPES = [(10, 1024), (10, 2048), (16, 512), (20, 512), (20, 1024), (40, 256), (40, 512), (80, 128)]
+
+
+def bench_dw(args):
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    bf = args.dtype == "bf16"
+    lib.casync_op_set_dtype(1 if bf else 0)
+    tdt = torch.bfloat16 if bf else torch.float32
+    for hw, c in DW_SHAPES:
+        B = args.batch
+        x = torch.randn(B, hw, hw, c, device=DEV).to(tdt)
+        w, b = torch.randn(9, c, device=DEV) / 3, torch.randn(c, device=DEV)
+        out = torch.empty_like(x)
+
+        def fn():
+            st = lib.casync_op_dw3x3(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), B, hw, hw, c, 1, s)
+            assert st == 0, lib.casync_last_error()
+        ms = time_ms(fn, args.iters)
+        gb = 2 * x.numel() * x.element_size() / ms / 1e6
+        print(f"dw {hw:3d}x{hw:<3d} C={c:5d}  {ms * 1e3:8.1f} us  {gb:7.1f} GB/s", flush=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["ir", "gemm"])
+    ap.add_argument("what", choices=["ir", "gemm", "dw"])
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--shape", default="")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     a = ap.parse_args()
-    {"ir": bench_ir, "gemm": bench_gemm}[a.what](a)
+    {"ir": bench_ir, "gemm": bench_gemm, "dw": bench_dw}[a.what](a)
