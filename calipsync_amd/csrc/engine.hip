@@ -656,9 +656,10 @@ static int ensure_streams(casync_handle h) {
   return CASYNC_OK;
 }
 
-// Lanes pay off once each half-batch still fills the chip (measured: B=8 -16 %, B=16 +-0, B=32 +7 %,
-// B=64 +4 % with two lanes; tools/latency_sweep.py).
-constexpr int kMinLaneBatch = 12;
+// One lane + stream-K GEMMs below 32 frames, two plain-tile lanes from there on (measured with
+// tools/latency_sweep.py, one lane vs two: B=8 +19 %, B=24 +4 %, B=32 -3.5 %, B=64 +-0.5 %,
+// B=96 -3.4 %, B=256 -0.4 %; bf16 B=64..512 -1.5..-3 %).
+constexpr int kMinLaneBatch = 16;
 
 static int forward_impl(casync_handle h, const float* x, const float* a, const float* feat, int n_steps,
                         const int* idx, float* out, int batch, void* ws, int64_t ws_bytes,

@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
 
 template <typename T, int BM, int BN, int WM, int WN, int NST>
 int launch_glds_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, int k,
-                  const GemmEpilogue& epi, hipStream_t stream) {
+                  const GemmEpilogue& epi, hipStream_t stream, bool use_sk) {
   constexpr size_t lds = (size_t)NST * (BM + BN) * ROWB;
   static bool attr_set = false;
   auto kern = pw_gemm_glds_kernel<T, BM, BN, WM, WN, NST>;
@@ -517,7 +517,7 @@ int launch_glds_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, 
   CASYNC_REQUIRE(nwg < (1ll << 31), "gemm grid too large");
   constexpr int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
   const long long cap = 256ll * per_cu;
-  const StreamKSplit sk = stream_k_split(nwg, k / (ROWB / (int)sizeof(T)), BM * BN, epi.sk_ws != nullptr);
+  const StreamKSplit sk = stream_k_split(nwg, k / (ROWB / (int)sizeof(T)), BM * BN, epi.sk_ws != nullptr && use_sk);
   const long long want = sk.dp_tiles + sk.wgs;
   const unsigned grid = (unsigned)(want > cap ? cap : want);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a, lda, w, c, ldc, m, n, k, n_ntiles,
@@ -558,7 +558,7 @@ inline int glds_mode() {
 
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, int n, int k,
-               const GemmEpilogue& epi, hipStream_t stream, int dtype) {
+               const GemmEpilogue& epi, hipStream_t stream, int dtype, bool use_sk) {
   // ring depth: 128x128 -> 3 stages (96 KB, one workgroup per CU), 128x64 -> 2 stages (48 KB, three
   // per CU), 64x64 -> 3 stages (48 KB, three per CU).  Measured: one more co-resident workgroup
   // beats one more stage of prefetch (+1.5 % fp32, +3.6 % bf16 end to end).
@@ -572,11 +572,11 @@ int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, i
     if (ring_ok && dtype == DT_BF16 && glds_mode() >= 1)
       return launch_glds_t<bf16_t, BM, BN, WM, WN, NST>(static_cast<const bf16_t*>(a), lda,
                                                         static_cast<const bf16_t*>(w), static_cast<bf16_t*>(c),
-                                                        ldc, m, n, k, epi, stream);
+                                                        ldc, m, n, k, epi, stream, use_sk);
     if (ring_ok && dtype == DT_F32 && glds_mode() >= 2)
       return launch_glds_t<float, BM, BN, WM, WN, NST>(static_cast<const float*>(a), lda,
                                                        static_cast<const float*>(w), static_cast<float*>(c), ldc,
-                                                       m, n, k, epi, stream);
+                                                       m, n, k, epi, stream, use_sk);
   }
   if (dtype == DT_BF16)
     return launch_cfg_t<bf16_t, BM, BN, WM, WN>(static_cast<const bf16_t*>(a), lda, static_cast<const bf16_t*>(w),
@@ -600,9 +600,16 @@ bool takes_ring(const TileCfg& t, long long tiles, int dtype) {
          ((dtype == DT_BF16 && glds_mode() >= 1) || (dtype == DT_F32 && glds_mode() >= 2));
 }
 
-int pick_cfg(int m, int n, int k, bool stream_k, int dtype) {
+int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullptr) {
   static const int forced = [] { const char* v = getenv("CASYNC_GEMM_CFG"); return v ? atoi(v) : -1; }();
-  if (forced >= 0 && forced < CFG_COUNT && n % kTiles[forced].bn == 0) return forced;
+  const int nk = k / (ROWB / dtype_size(dtype));
+  if (use_sk) *use_sk = false;
+  if (forced >= 0 && forced < CFG_COUNT && n % kTiles[forced].bn == 0) {
+    const TileCfg& t = kTiles[forced];
+    const long long g = (long long)((m + t.bm - 1) / t.bm) * (n / t.bn);
+    if (use_sk) *use_sk = takes_ring(t, g, dtype) && stream_k_split(g, nk, t.bm * t.bn, stream_k).wgs > 0;
+    return forced;
+  }
   // Cost model fitted to tools/experiments/streamk_sweep.sh: a launch costs a fixed ~17 us (not
   // modelled, equal for all) plus rounds x nk x (area + 600) / 8192 us, where a "round" is one
   // tile per CU (co-resident tiles share the CU's matrix pipes, so they add, not overlap) and the
@@ -611,17 +618,20 @@ int pick_cfg(int m, int n, int k, bool stream_k, int dtype) {
   // a little higher here so that it is only chosen where it clearly wins).
   int best = -1;
   double best_cost = 0;
-  const int nk = k / (ROWB / dtype_size(dtype));
   for (const TileCfg& t : kTiles) {
     if (n % t.bn || t.id >= C64x32) continue;   // experimental configs: only when forced
     const long long g = (long long)((m + t.bm - 1) / t.bm) * (n / t.bn);
-    double rounds = (double)((g + 255) / 256), extra = 0.0;
-    if (takes_ring(t, g, dtype)) {
-      const StreamKSplit sk = stream_k_split(g, nk, t.bm * t.bn, stream_k);
-      if (sk.wgs) rounds = (double)g / 256.0, extra = 2.5 + 9.5 * (t.bm * t.bn) / 8192.0;
+    const double per_round = nk * (t.bm * t.bn + 600.0) / 8192.0;
+    double cost = (double)((g + 255) / 256) * per_round;
+    bool sk_better = false;
+    if (takes_ring(t, g, dtype) && stream_k_split(g, nk, t.bm * t.bn, stream_k).wgs) {
+      const double sk_cost = (double)g / 256.0 * per_round + 2.5 + 9.5 * (t.bm * t.bn) / 8192.0;
+      if (sk_cost < cost) cost = sk_cost, sk_better = true;
     }
-    const double cost = rounds * nk * (t.bm * t.bn + 600.0) / 8192.0 + extra;
-    if (best < 0 || cost < best_cost) best = t.id, best_cost = cost;
+    if (best < 0 || cost < best_cost) {
+      best = t.id, best_cost = cost;
+      if (use_sk) *use_sk = sk_better;
+    }
   }
   return best;
 }
@@ -668,12 +678,13 @@ int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int 
   CASYNC_REQUIRE((!epi.pre_res || epi.ld_pre % 4 == 0) && (!epi.post_res || epi.ld_post % 4 == 0) &&
                      (!epi.acc_out || epi.ld_acc % 4 == 0),
                  "pw_gemm: residual leading dimensions must be multiples of 4");
-  switch (pick_cfg(m, n, k, epi.sk_ws != nullptr, dtype)) {
-    case C128x128: return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype);
-    case C128x64: return launch_cfg<128, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype);
-    case C64x64: return launch_cfg<64, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype);
-    case C64x32: return launch_cfg<64, 32, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype);
-    case C64x64W2: return launch_cfg<64, 64, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype);
-    default: return launch_cfg<128, 32, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype);
+  bool sk = false;
+  switch (pick_cfg(m, n, k, epi.sk_ws != nullptr, dtype, &sk)) {
+    case C128x128: return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
+    case C128x64: return launch_cfg<128, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
+    case C64x64: return launch_cfg<64, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
+    case C64x32: return launch_cfg<64, 32, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
+    case C64x64W2: return launch_cfg<64, 64, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
+    default: return launch_cfg<128, 32, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
   }
 }
