@@ -198,12 +198,23 @@ def main():
             "unit": "TFLOP/s" if mfma_bound else "GB/s",
             "frac": round((tf / mfma_peak) if mfma_bound else (gbs / HBM_PEAK_GBS), 4),
             "traffic": None,
+            "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]),
             "launches_per_step": dom["n"] // reps,
             "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
             "share_of_step": round(dom["ms"] / sum(c["ms"] for c in per.values()), 3),
             "measured": "HIP events around every launch, isolated single-lane replay of the same batch "
                         "(profiles/r1_final_kernel_stats_lanes1.csv is rocprofv3 of that mode)",
         }
+        # HBM-side bytes per launch of that kernel from the committed PMC passes (collected with
+        # tools/collect_profiles.sh in this same replay mode; B=64 fp32 only -- the counters are per
+        # launch, so they do not depend on the step count)
+        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
+        if args.dtype == "f32" and B == 64 and os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file))
+            hit = pmc["kernels"].get(dom_name)
+            if hit:
+                roofline["traffic"] = hit["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/r1_pmc_traffic.json: " + pmc["source"]
         work = arch.work_per_frame()
         canon_bytes = work["canonical_bytes_f32"] // (1 if args.dtype == "f32" else 2)
         fps = world * B * args.steps / dt
