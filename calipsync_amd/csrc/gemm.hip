@@ -56,6 +56,68 @@ template <> struct MfmaK<bf16_t> {
   }
 };
 
+// Epilogue rows shared by both GEMM kernels: the fp32 C tile staged row-major in LDS ->
+// bias, scaled pre-residual, LReLU, post-residual, second affine + LReLU, running-sum output,
+// with one 16-B global access per thread and tensor (4 fp32 or 8 bf16 columns), rows coalesced.
+template <typename T, int NT, int BM, int BN>
+__device__ __forceinline__ void epilogue_rows(const float* Cs, int m0, int n0, int M, T* __restrict__ C,
+                                              int ldc, const GemmEpilogue& epi, int tid) {
+  constexpr int CPT = V16<T>::N, TPR = BN / CPT, RPP = NT / TPR, LDC_S = BN + 4;
+  static_assert(BN % CPT == 0 && NT % TPR == 0 && BM % RPP == 0, "epilogue thread map");
+  const int c0 = (tid % TPR) * CPT, rr = tid / TPR, n = n0 + c0;
+  float bias[CPT], pscale[CPT], as[CPT], at[CPT];
+#pragma unroll
+  for (int e = 0; e < CPT; e += 4) {
+    const f32x4 b = epi.bias ? *reinterpret_cast<const f32x4*>(epi.bias + n + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 p = epi.pre_scale ? *reinterpret_cast<const f32x4*>(epi.pre_scale + n + e) : f32x4{1.f, 1.f, 1.f, 1.f};
+    const f32x4 s = epi.aff_s ? *reinterpret_cast<const f32x4*>(epi.aff_s + n + e) : f32x4{1.f, 1.f, 1.f, 1.f};
+    const f32x4 t = epi.aff_s ? *reinterpret_cast<const f32x4*>(epi.aff_t + n + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bias[e + q] = b[q], pscale[e + q] = p[q], as[e + q] = s[q], at[e + q] = t[q];
+  }
+#pragma unroll 4
+  for (int p = 0; p < BM / RPP; ++p) {
+    const int row = rr + RPP * p, m = m0 + row;
+    if (m >= M) break;
+    V16<T> v;
+#pragma unroll
+    for (int e = 0; e < CPT; e += 4) {
+      const f32x4 c = *reinterpret_cast<const f32x4*>(Cs + row * LDC_S + c0 + e);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v.v[e + q] = c[q] + bias[e + q];
+    }
+    if (epi.pre_res) {
+      const V16<T> r = ld16(static_cast<const T*>(epi.pre_res) + (size_t)m * epi.ld_pre + n);
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) v.v[e] += pscale[e] * r.v[e];
+    }
+    if (epi.act) {
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) v.v[e] = lrelu(v.v[e]);
+    }
+    if (epi.post_res) {
+      const V16<T> r = ld16(static_cast<const T*>(epi.post_res) + (size_t)m * epi.ld_post + n);
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) v.v[e] += r.v[e];
+    }
+    if (epi.aff_s && !epi.aff_on_acc) {
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) v.v[e] = lrelu(v.v[e] * as[e] + at[e]);
+    }
+    st16(C + (size_t)m * ldc + n, v);
+    if (epi.acc_out) {
+      V16<T> sacc = ld16(static_cast<const T*>(epi.acc_in) + (size_t)m * epi.ld_acc + n);
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) sacc.v[e] += v.v[e];
+      if (epi.aff_s && epi.aff_on_acc) {
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) sacc.v[e] = lrelu(sacc.v[e] * as[e] + at[e]);
+      }
+      st16(static_cast<T*>(epi.acc_out) + (size_t)m * epi.ld_acc + n, sacc);
+    }
+  }
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void pw_gemm_kernel(const T* __restrict__ A, int lda,
                                                       const T* __restrict__ W, T* __restrict__ C,
@@ -122,10 +184,6 @@ __global__ __launch_bounds__(64 * WM * WN) void pw_gemm_kernel(const T* __restri
   };
 
   // epilogue constants that do not depend on the tile row
-  constexpr int TPR = BN / 4;          // threads per output row
-  constexpr int RPP = NT / TPR;        // rows per pass
-  const int c4 = (tid % TPR) * 4, rr = tid / TPR;
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
 
   // Persistent over tiles: the first k-tile of the NEXT tile is fetched into registers while
   // the last k-tile of this one computes, so its HBM latency hides under the MFMAs and the
@@ -189,34 +247,8 @@ __global__ __launch_bounds__(64 * WM * WN) void pw_gemm_kernel(const T* __restri
       }
     __syncthreads();
 
-    // ---- epilogue 2: float4 rows: bias, residuals, activation, coalesced stores ----
-    const int n = n0 + c4;
-    const f32x4 bias = epi.bias ? *reinterpret_cast<const f32x4*>(epi.bias + n) : zero;
-    const f32x4 pscale = epi.pre_scale ? *reinterpret_cast<const f32x4*>(epi.pre_scale + n) : one;
-    const f32x4 as = epi.aff_s ? *reinterpret_cast<const f32x4*>(epi.aff_s + n) : one;
-    const f32x4 at = epi.aff_s ? *reinterpret_cast<const f32x4*>(epi.aff_t + n) : zero;
-#pragma unroll 4
-    for (int p = 0; p < BM / RPP; ++p) {
-      const int row = rr + RPP * p, m = m0 + row;
-      if (m >= M) break;
-      f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC_S + c4) + bias;
-      if (epi.pre_res) v += pscale * ld4(static_cast<const T*>(epi.pre_res) + (size_t)m * epi.ld_pre + n);
-      if (epi.act) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
-      if (epi.post_res) v += ld4(static_cast<const T*>(epi.post_res) + (size_t)m * epi.ld_post + n);
-      if (epi.aff_s && !epi.aff_on_acc) {
-        v = v * as + at;
-        v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w);
-      }
-      st4(C + (size_t)m * ldc + n, v);
-      if (epi.acc_out) {
-        f32x4 s = ld4(static_cast<const T*>(epi.acc_in) + (size_t)m * epi.ld_acc + n) + v;
-        if (epi.aff_s && epi.aff_on_acc) {
-          s = s * as + at;
-          s.x = lrelu(s.x); s.y = lrelu(s.y); s.z = lrelu(s.z); s.w = lrelu(s.w);
-        }
-        st4(static_cast<T*>(epi.acc_out) + (size_t)m * epi.ld_acc + n, s);
-      }
-    }
+    // ---- epilogue 2: bias, residuals, activation, coalesced 16-B stores ----
+    epilogue_rows<T, NT, BM, BN>(Cs, m0, n0, M, C, ldc, epi, tid);
     __syncthreads();  // the C tile aliases the staging buffers the next tile is about to fill
     m0 = m0n;
     n0 = n0n;
@@ -292,9 +324,6 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
   const int lrow8 = lane >> 3, lcol = lane & 7;
 
   // epilogue constants
-  constexpr int TPR = BN / 4, RPP = 256 / TPR;
-  const int c4 = (tid % TPR) * 4, rr = tid / TPR;
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, one = {1.f, 1.f, 1.f, 1.f};
 
   f32x16 acc[TM][TN];
   int m0 = 0, n0 = 0;
@@ -398,33 +427,7 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
       }
     __syncthreads();
 
-    const int n = n0 + c4;
-    const f32x4 bias = epi.bias ? *reinterpret_cast<const f32x4*>(epi.bias + n) : zero;
-    const f32x4 pscale = epi.pre_scale ? *reinterpret_cast<const f32x4*>(epi.pre_scale + n) : one;
-    const f32x4 as = epi.aff_s ? *reinterpret_cast<const f32x4*>(epi.aff_s + n) : one;
-    const f32x4 at = epi.aff_s ? *reinterpret_cast<const f32x4*>(epi.aff_t + n) : zero;
-#pragma unroll 4
-    for (int p = 0; p < BM / RPP; ++p) {
-      const int row = rr + RPP * p, m = m0 + row;
-      if (m >= M) break;
-      f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC_S + c4) + bias;
-      if (epi.pre_res) v += pscale * ld4(static_cast<const T*>(epi.pre_res) + (size_t)m * epi.ld_pre + n);
-      if (epi.act) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
-      if (epi.post_res) v += ld4(static_cast<const T*>(epi.post_res) + (size_t)m * epi.ld_post + n);
-      if (epi.aff_s && !epi.aff_on_acc) {
-        v = v * as + at;
-        v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w);
-      }
-      st4(C + (size_t)m * ldc + n, v);
-      if (epi.acc_out) {
-        f32x4 s = ld4(static_cast<const T*>(epi.acc_in) + (size_t)m * epi.ld_acc + n) + v;
-        if (epi.aff_s && epi.aff_on_acc) {
-          s = s * as + at;
-          s.x = lrelu(s.x); s.y = lrelu(s.y); s.z = lrelu(s.z); s.w = lrelu(s.w);
-        }
-        st4(static_cast<T*>(epi.acc_out) + (size_t)m * epi.ld_acc + n, s);
-      }
-    }
+    epilogue_rows<T, 256, BM, BN>(Cs, m0, n0, M, C, ldc, epi, tid);
     __syncthreads();   // C tile consumed before the next loads overwrite the ring
   };
 
@@ -671,13 +674,16 @@ int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int 
   CASYNC_REQUIRE(k % bk == 0, "pw_gemm: K=%d must be a multiple of %d", k, bk);
   CASYNC_REQUIRE(n % 32 == 0, "pw_gemm: N=%d must be a multiple of 32", n);
   CASYNC_REQUIRE(lda % e16 == 0 && lda >= k, "pw_gemm: lda=%d (K=%d) must be >= K and a multiple of %d", lda, k, e16);
-  CASYNC_REQUIRE(ldc >= n && ldc % 4 == 0, "pw_gemm: ldc=%d must be >= N=%d and a multiple of 4", ldc, n);
+  CASYNC_REQUIRE(ldc >= n && ldc % e16 == 0, "pw_gemm: ldc=%d must be >= N=%d and a multiple of %d", ldc, n, e16);
   CASYNC_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)c % 16) == 0,
                  "pw_gemm: A/W/C must be 16-B aligned");
   CASYNC_REQUIRE(!epi.acc_out || epi.acc_in, "pw_gemm: acc_out without acc_in");
-  CASYNC_REQUIRE((!epi.pre_res || epi.ld_pre % 4 == 0) && (!epi.post_res || epi.ld_post % 4 == 0) &&
-                     (!epi.acc_out || epi.ld_acc % 4 == 0),
-                 "pw_gemm: residual leading dimensions must be multiples of 4");
+  CASYNC_REQUIRE((!epi.pre_res || epi.ld_pre % e16 == 0) && (!epi.post_res || epi.ld_post % e16 == 0) &&
+                     (!epi.acc_out || epi.ld_acc % e16 == 0),
+                 "pw_gemm: residual leading dimensions must be multiples of %d", e16);
+  CASYNC_REQUIRE((!epi.pre_res || (uintptr_t)epi.pre_res % 16 == 0) && (!epi.post_res || (uintptr_t)epi.post_res % 16 == 0) &&
+                     (!epi.acc_out || ((uintptr_t)epi.acc_out % 16 == 0 && (uintptr_t)epi.acc_in % 16 == 0)),
+                 "pw_gemm: residual pointers must be 16-B aligned");
   bool sk = false;
   switch (pick_cfg(m, n, k, epi.sk_ws != nullptr, dtype, &sk)) {
     case C128x128: return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
