@@ -5,10 +5,12 @@
 //   out[i][c] = gamma * sum_j P[i][j] V[j][c] + res[i][c]
 //
 // Q, K, V come from the 1x1 projections (NHWC rows: position-major, channel contiguous).
-// One workgroup = 32 query rows x 128 value channels of one frame (grid = B x 4 x 4); the
-// 32x100 score tile lives in LDS only (recomputed per channel chunk: QK^T is ~10 % of the work).
-// The V chunk is fetched into registers at kernel entry and parked in LDS over the dead K tile,
-// so its HBM/L2 latency hides under the staging, QK^T and softmax phases.  QK^T and PV run on
+// One workgroup = 32 query rows of one frame x 512/nz value channels, walked in 128-channel chunks
+// (grid = B x 4 x nz).  The 32x100 score tile lives in LDS only and is computed once per
+// workgroup; nz = 4 (one chunk each, scores recomputed: QK^T is ~10 % of the work) fills the chip
+// at small batches, nz = 1 avoids the 4x Q/K re-reads once B x 4 workgroups are plenty.
+// Each V chunk is fetched into registers ahead of time (the first at kernel entry, the next under
+// the previous chunk's PV) and parked in LDS over the dead K tile, so its HBM/L2 latency hides.  QK^T and PV run on
 // v_mfma_f32_32x32x2_f32; the row softmax is a 64-lane shuffle reduction (two keys per lane).
 #include "common.h"
 
@@ -48,7 +50,8 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(
   float* Ss = att_lds + oS;
   float* Ks = att_lds + oKV;   // [128][QLD] during QK^T
   float* Vs = att_lds + oKV;   // [100][VLD] during PV (after the scores are done with K)
-  const int b = blockIdx.x, qb = blockIdx.y, cz = blockIdx.z;   // frame, 32-query block, 128-channel chunk
+  const int b = blockIdx.x, qb = blockIdx.y;                    // frame, 32-query block
+  const int cpw = 4 / (int)gridDim.z, cz0 = blockIdx.z * cpw;   // this workgroup's 128-channel chunks
   const size_t row0 = (size_t)b * NP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r32 = lane & 31, kh = lane >> 5;
@@ -56,11 +59,14 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(
   // ---- the V chunk [100 keys][128 channels] starts its trip from HBM/L2 now and is parked in
   //      registers until K is dead (it arrives under the staging, QK^T and softmax phases) ----
   f32x4 vreg[VREGS];
+  auto vfetch = [&](int cz) {
 #pragma unroll
-  for (int j = 0; j < VREGS; ++j) {
-    const int idx = tid + 256 * j;                // float4 index: key = idx/32, 4 channels at (idx%32)*4
-    if (idx < NP * 32) vreg[j] = ld4(v + (row0 + (idx >> 5)) * ldv + cz * 128 + (idx & 31) * 4);
-  }
+    for (int j = 0; j < VREGS; ++j) {
+      const int idx = tid + 256 * j;              // float4 index: key = idx/32, 4 channels at (idx%32)*4
+      if (idx < NP * 32) vreg[j] = ld4(v + (row0 + (idx >> 5)) * ldv + cz * 128 + (idx & 31) * 4);
+    }
+  };
+  vfetch(cz0);
 
   // ---- stage Q block and all K rows (rows >= 100 are zero) ----
   {
@@ -104,49 +110,57 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(
   }
   __syncthreads();   // scores complete, K dead
 
-  // ---- park V in LDS (over K) and run the row softmax: wave w owns rows 8w .. 8w+7 ----
-#pragma unroll
-  for (int j = 0; j < VREGS; ++j) {
-    const int idx = tid + 256 * j;
-    if (idx < NP * 32) *reinterpret_cast<f32x4*>(Vs + (idx >> 5) * VLD + (idx & 31) * 4) = vreg[j];
-  }
-#pragma unroll
-  for (int rr = 0; rr < 8; ++rr) {
-    float* srow = Ss + (wave * 8 + rr) * SLD;
-    const bool has2 = lane + 64 < NP;
-    const float e0 = srow[lane];
-    const float e1 = has2 ? srow[lane + 64] : -INFINITY;
-    const float mx = wave_max(fmaxf(e0, e1));
-    const float p0 = expf(e0 - mx);
-    const float p1 = has2 ? expf(e1 - mx) : 0.f;
-    const float inv = 1.f / wave_sum(p0 + p1);
-    srow[lane] = p0 * inv;
-    srow[lane + 64] = p1 * inv;  // keys 100..127 become exact zeros
-  }
-  __syncthreads();
-
-  // ---- out = P V: wave w owns channels 32w .. 32w+31 of this block's 128-channel chunk ----
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const float* pa = Ss + r32 * SLD + 4 * kh;
-  const float* vb = Vs + wave * 32 + r32;
-#pragma unroll
-  for (int g = 0; g < 13; ++g) {  // 13 groups of 8 keys cover 0..103; P is zero past 99
-    const f32x4 fa = *reinterpret_cast<const f32x4*>(pa + 8 * g);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      int key = 8 * g + 4 * kh + s;
-      key = key < NP ? key : NP - 1;  // stay inside the staged rows (weight is 0 there)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], vb[key * VLD], acc, 0, 0, 0);
-    }
-  }
   const float gam = gamma[0];
-  const int c = cz * 128 + wave * 32 + r32;
+  for (int ci = 0; ci < cpw; ++ci) {
+    const int cz = cz0 + ci;
+    // ---- park this chunk's V in LDS (over K / the previous chunk) ----
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-    if (qi < NP) out[(row0 + qi) * ld_out + c] = (T)(gam * acc[r] + (float)res[(row0 + qi) * ld_res + c]);
+    for (int j = 0; j < VREGS; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < NP * 32) *reinterpret_cast<f32x4*>(Vs + (idx >> 5) * VLD + (idx & 31) * 4) = vreg[j];
+    }
+    if (ci == 0) {
+      // ---- row softmax: wave w owns rows 8w .. 8w+7 ----
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        float* srow = Ss + (wave * 8 + rr) * SLD;
+        const bool has2 = lane + 64 < NP;
+        const float e0 = srow[lane];
+        const float e1 = has2 ? srow[lane + 64] : -INFINITY;
+        const float mx = wave_max(fmaxf(e0, e1));
+        const float p0 = expf(e0 - mx);
+        const float p1 = has2 ? expf(e1 - mx) : 0.f;
+        const float inv = 1.f / wave_sum(p0 + p1);
+        srow[lane] = p0 * inv;
+        srow[lane + 64] = p1 * inv;  // keys 100..127 become exact zeros
+      }
+    }
+    __syncthreads();
+    if (ci + 1 < cpw) vfetch(cz + 1);   // next chunk's V travels under this chunk's PV
+
+    // ---- out = P V: wave w owns channels 32w .. 32w+31 of the 128-channel chunk ----
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* pa = Ss + r32 * SLD + 4 * kh;
+    const float* vb = Vs + wave * 32 + r32;
+#pragma unroll
+    for (int g = 0; g < 13; ++g) {  // 13 groups of 8 keys cover 0..103; P is zero past 99
+      const f32x4 fa = *reinterpret_cast<const f32x4*>(pa + 8 * g);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        int key = 8 * g + 4 * kh + s;
+        key = key < NP ? key : NP - 1;  // stay inside the staged rows (weight is 0 there)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], vb[key * VLD], acc, 0, 0, 0);
+      }
+    }
+    const int c = cz * 128 + wave * 32 + r32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (qi < NP) out[(row0 + qi) * ld_out + c] = (T)(gam * acc[r] + (float)res[(row0 + qi) * ld_res + c]);
+    }
+    if (ci + 1 < cpw) __syncthreads();   // everyone is done with Vs before the next chunk is parked
   }
 }
 
@@ -169,7 +183,11 @@ int launch_cross_attention(const void* q, int ldq, const void* k, int ldk, const
                                          hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES));
     attr_set = true;
   }
-  const dim3 grid(batch, 4, 4);   // frame x 32-query block x 128-channel chunk
+  // frame x 32-query block x channel split: enough workgroups to fill 256 CUs x ~4, no more
+  static const int forced_nz = [] { const char* e = getenv("CASYNC_ATT_NZ"); return e && *e ? atoi(e) : 0; }();
+  int nz = batch <= 64 ? 4 : (batch <= 160 ? 2 : 1);
+  if (forced_nz == 1 || forced_nz == 2 || forced_nz == 4) nz = forced_nz;
+  const dim3 grid(batch, 4, nz);
   if (dtype == DT_BF16)
     hipLaunchKernelGGL(cross_attention_kernel<bf16_t>, grid, dim3(256), ATT_LDS_BYTES, stream, (const bf16_t*)q,
                        ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)res, ld_res, gamma_dev,
