@@ -102,3 +102,15 @@ def test_create_without_gpu_reports_no_device(lib):
     h = ctypes.c_void_p()
     assert lib.casync_create(0, ctypes.byref(h)) < 0
     assert b"device" in lib.casync_last_error()
+
+
+def test_header_is_c99_and_a_plain_c_host_can_bind_it(lib, tmp_path):
+    """The boundary is a C ABI, not a Python extension: tests/c/abi_host.c includes the header as
+    C99 (-Wall -Werror), dlopens the library and walks the packed layout without Python."""
+    import subprocess
+    exe = tmp_path / "abi_host"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"),
+                    os.path.join(REPO, "tests", "c", "abi_host.c"), "-ldl", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe), _lib.lib_path()], check=True, capture_output=True, text=True).stdout
+    items, total = _lib.packed_layout()
+    assert f"abi 1 tensors {len(items)} " in out and f"total {total} " in out and "gammas 4" in out
