@@ -219,6 +219,7 @@ def main():
         canon_bytes = work["canonical_bytes_f32"] // (1 if args.dtype == "f32" else 2)
         fps = world * B * args.steps / dt
         per_gpu = fps / world
+        stage = arch.stagewise_bound(mfma_peak * 1e12, HBM_PEAK_GBS * 1e9, 4 if args.dtype == "f32" else 2)
         result = {
             "metric": "160x160 lip-sync frames/sec (whole node)",
             "value": round(fps, 1),
@@ -242,7 +243,10 @@ def main():
             "whole_net": {"mfma_frac": round(per_gpu * work["flops"] / (mfma_peak * 1e12), 4),
                           "hbm_frac_canonical": round(per_gpu * canon_bytes / (HBM_PEAK_GBS * 1e9), 4),
                           "gflop_per_frame": round(work["flops"] / 1e9, 3),
-                          "canonical_mb_per_frame": round(canon_bytes / 1e6, 2)},
+                          "canonical_mb_per_frame": round(canon_bytes / 1e6, 2),
+                          # per stage max(canonical bytes / 8 TB/s, flops / matrix peak), summed
+                          "stagewise_bound_fps_per_gpu": round(stage["frames_per_s"], 1),
+                          "frac_of_stagewise_bound": round(per_gpu / stage["frames_per_s"], 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd_np, args.cpu_seconds)

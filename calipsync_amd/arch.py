@@ -185,6 +185,43 @@ def manifest() -> List[Entry]:
 # --------------------------------------------------------------------------
 # Work figures per frame -- used by bench.py's roofline block
 # --------------------------------------------------------------------------
+def stagewise_bound(peak_flops: float, peak_bytes_per_s: float, elem_bytes: int = 4) -> dict:
+    """SURVEY.md 8(d) "stage-wise" roofline: per stage (inc, down1-4, audio encoder, MLP fusion,
+    each attention block, fuse_conv, up1-4, outc) max(canonical bytes / HBM peak, flops / matrix
+    peak), summed -- the bound the north star's "60 % of the governing roofline" is priced on
+    (fp32: 60.7 us/frame = 16.5 k frames/s per GPU)."""
+    stages: dict = {}
+
+    def conv(stage, cin, cout, hw_in, hw_out, k, groups=1):
+        st = stages.setdefault(stage, [0, 0])
+        st[0] += 2 * hw_out * hw_out * cout * (cin // groups) * k * k
+        st[1] += (cin * hw_in * hw_in + cout * hw_out * hw_out) * elem_bytes
+
+    for b in all_ir_blocks():
+        stage = b.prefix.split(".")[0]
+        conv(stage, b.cin, b.cexp, b.hw_in, b.hw_in, 1)
+        conv(stage, b.cexp, b.cexp, b.hw_in, b.hw_out, 3, groups=b.cexp)
+        conv(stage, b.cexp, b.cout, b.hw_out, b.hw_out, 1)
+    conv("audio_model", CH[2], CH[3], 32, 16, 3)
+    conv("audio_model", CH[3], CH[4], 16, 10, 3)
+    c2 = CH[4] * 2
+    conv("mlp", c2, c2, 10, 10, 1)
+    conv("mlp", c2, c2, 10, 10, 1)
+    for i in range(N_ATT_BLOCKS):
+        st = f"attention_blocks.{i}"
+        conv(st, c2, CH[4], 10, 10, 1)
+        conv(st, CH[4], CH[4] // 8, 10, 10, 1)
+        conv(st, CH[4], CH[4] // 8, 10, 10, 1)
+        conv(st, CH[4], CH[4], 10, 10, 1)
+        conv(st, CH[4], c2, 10, 10, 1)
+        stages[st][0] += 2 * (100 * 100 * (CH[4] // 8) + 100 * 100 * CH[4])
+    conv("outc", CH[0], 3, 160, 160, 1)
+    per = {k: max(v[1] / peak_bytes_per_s, v[0] / peak_flops) for k, v in stages.items()}
+    total = sum(per.values())
+    return {"seconds_per_frame": total, "frames_per_s": 1.0 / total,
+            "hbm_governed": sorted(k for k, v in stages.items() if v[1] / peak_bytes_per_s >= v[0] / peak_flops)}
+
+
 def work_per_frame() -> dict:
     """MACs and canonical conv-granularity activation elements per frame.
 

@@ -52,3 +52,13 @@ def test_inputs_are_shard_invariant():
     x, a = recipe.make_inputs(3)
     x2, a2 = recipe.make_inputs_range(1, 2)
     assert np.array_equal(x[1:], x2) and np.array_equal(a[1:], a2)
+
+
+def test_stagewise_bound_matches_survey():
+    """fp32 stage-wise bound 60.7 us/frame = 16.5 k frames/s per GPU, HBM governs inc, down1,
+    up3, up4, outc; bf16 57.6-57.8 k frames/s with HBM governing (almost) everywhere."""
+    f32 = arch.stagewise_bound(157.3e12, 8e12, 4)
+    assert abs(f32["seconds_per_frame"] * 1e6 - 60.7) < 0.05
+    assert f32["hbm_governed"] == ["down1", "inc", "outc", "up3", "up4"]
+    bf16 = arch.stagewise_bound(2.5e15, 8e12, 2)
+    assert 57.5e3 < bf16["frames_per_s"] < 57.9e3 and "mlp" not in bf16["hbm_governed"]
