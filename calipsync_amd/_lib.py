@@ -81,6 +81,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64: it must be in the process before this library resolves its
+    # HIP dependency, or two HIP runtimes get loaded and the second one sees no device
+    # ("create: no HIP device visible" when the engine was loaded before `import torch`).
+    import torch  # noqa: F401
     path = lib_path()
     if not os.path.exists(path):
         raise RuntimeError(
