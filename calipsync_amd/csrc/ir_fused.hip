@@ -280,33 +280,40 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
       if (ch + 2 < NCH) wload((ch + 2) * CC);     // and start fetching the one after
     }
 
-    // ---- P2: depthwise 3x3 over E -> D (thread = 4 channels x several pixels).  E is read
-    //      linearly (consecutive lanes = consecutive 16-B columns of consecutive pixels), so it
-    //      needs no swizzle; taps are the outer loop so only one weight vector is live ----
+    // ---- P2: depthwise 3x3 over E -> D.  Thread = 4 channels x NPX pixels STACKED IN Y, so the
+    //      (NPX-1)*STRIDE+3 tap rows are read once and shared (12 instead of 18 E reads for two
+    //      pixels); consecutive lanes still walk consecutive 16-B columns of consecutive pixels
+    //      in x, so E needs no swizzle ----
     {
-      constexpr int TPP = CC / 4, PPI = 256 / TPP, NPX = G::OP / PPI;
+      constexpr int TPP = CC / 4, PPI = 256 / TPP, NPX = G::OP / PPI, NROW = (NPX - 1) * STRIDE + 3;
+      static_assert(PPI % TW == 0 && G::TH % NPX == 0, "P2 thread map");
       const int c4 = (tid % TPP) * 4, p0 = tid / TPP;
+      const int px = p0 % TW, py0 = (p0 / TW) * NPX;
+      const float* eb = sE + ((py0 * STRIDE) * G::IW + px * STRIDE) * CC + c4;
       const f32x4 bv = *reinterpret_cast<const f32x4*>(wb + G::wB + CC + c4);
       f32x4 a[NPX];
-      const float* e0[NPX];
 #pragma unroll
-      for (int j = 0; j < NPX; ++j) {
-        const int p = p0 + PPI * j, py = p / TW, px = p - py * TW;
-        e0[j] = sE + ((py * STRIDE) * G::IW + px * STRIDE) * CC + c4;
-        a[j] = bv;
-      }
+      for (int j = 0; j < NPX; ++j) a[j] = bv;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const f32x4 wt = *reinterpret_cast<const f32x4*>(wb + G::wWd + t * CC + c4);
+      for (int kx = 0; kx < 3; ++kx) {   // one tap column at a time: only three weight vectors live
+        f32x4 wt[3];
 #pragma unroll
-        for (int j = 0; j < NPX; ++j)
-          a[j] += *reinterpret_cast<const f32x4*>(e0[j] + ((t / 3) * G::IW + (t % 3)) * CC) * wt;
+        for (int ky = 0; ky < 3; ++ky) wt[ky] = *reinterpret_cast<const f32x4*>(wb + G::wWd + (ky * 3 + kx) * CC + c4);
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) {
+          const f32x4 e = *reinterpret_cast<const f32x4*>(eb + (r * G::IW + kx) * CC);
+#pragma unroll
+          for (int j = 0; j < NPX; ++j) {
+            const int ky = r - j * STRIDE;
+            if (ky >= 0 && ky < 3) a[j] += e * wt[ky];
+          }
+        }
       }
 #pragma unroll
       for (int j = 0; j < NPX; ++j) {
         f32x4 v = a[j];
         v.x = lrelu_max(v.x); v.y = lrelu_max(v.y); v.z = lrelu_max(v.z); v.w = lrelu_max(v.w);
-        *reinterpret_cast<f32x4*>(sD + xs<CC>(p0 + PPI * j, c4)) = v;
+        *reinterpret_cast<f32x4*>(sD + xs<CC>((py0 + j) * TW + px, c4)) = v;
       }
     }
     __syncthreads();  // D complete (and the parked weights are visible)
