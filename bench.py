@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--kernel-table", action="store_true", help="print the per-launch table to stderr")
+    ap.add_argument("--replay-only", action="store_true",
+                    help="skip the timed region; run --steps isolated replays (the mode rocprofv3 / PMC passes "
+                         "are collected in, so their per-kernel figures match the roofline block)")
     return ap.parse_args()
 
 
@@ -149,10 +152,10 @@ def main():
         out = net(x, a)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(1 if args.replay_only else args.steps):
         out = net(x, a)
     sync()
-    dt = time.perf_counter() - t0
+    dt = (time.perf_counter() - t0) * (args.steps if args.replay_only else 1)
     if world > 1:
         t = torch.tensor([dt], device="cpu" if shared else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -164,13 +167,11 @@ def main():
     lanes = int(os.environ.get("CASYNC_LANES", "2"))
     if rank == 0:
         per = {}
-        reps = 3
-        # The timed region overlaps `lanes` half-batch lanes (and the audio stream) on the GPU, so
-        # per-kernel durations there are not separable.  The roofline pass therefore replays the
-        # SAME batch with the launches isolated: one lane, one stream, an event pair per launch.
-        os.environ["CASYNC_LANES"] = "1"
-        if lanes > 1:
-            os.environ["CASYNC_GEMM_STREAMK"] = "0"     # the timed multi-lane run uses plain tiles: replay those
+        reps = args.steps if args.replay_only else 3
+        # The timed region overlaps `lanes` sub-batch lanes (and the audio stream) on the GPU, so
+        # per-kernel durations there are not separable.  The roofline pass replays the SAME launches
+        # (same lanes, hence the same kernels, tile choices and grids) serialised on one stream with
+        # an event pair around each (casync_profile_forward).
         for _ in range(reps):
             for row in net.profile(x, a):
                 c = per.setdefault(row["kernel"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
@@ -184,7 +185,6 @@ def main():
             for r in rows:
                 print(f"  {r['name']:48s} {r['kernel']:38s} {r['ms']:8.3f} ms {r['flops'] / max(r['ms'], 1e-6) / 1e9:8.1f} TF "
                       f"{r['bytes'] / max(r['ms'], 1e-6) / 1e6:8.1f} GB/s", file=sys.stderr)
-        os.environ["CASYNC_LANES"] = str(lanes)
         dom_name, dom = max(per.items(), key=lambda kv: kv[1]["ms"])
         tf = dom["flops"] / dom["ms"] / 1e9
         gbs = dom["bytes"] / dom["ms"] / 1e6
@@ -202,11 +202,12 @@ def main():
             "launches_per_step": dom["n"] // reps,
             "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
             "share_of_step": round(dom["ms"] / sum(c["ms"] for c in per.values()), 3),
-            "measured": "HIP events around every launch, isolated single-lane replay of the same batch "
-                        "(profiles/r1_final_kernel_stats_lanes1.csv is rocprofv3 of that mode)",
+            "measured": "HIP events around every launch; the timed run's own launches (same lanes, tiles, grids) "
+                        "serialised on one stream; profiles/r1_final_kernel_stats_replay.csv is rocprofv3 "
+                        "--kernel-trace --stats of `bench.py --replay-only`",
         }
         # HBM-side bytes per launch of that kernel from the committed PMC passes (collected with
-        # tools/collect_profiles.sh in this same replay mode; B=64 fp32 only -- the counters are per
+        # tools/collect_profiles.sh with --replay-only, i.e. these same launches; B=64 fp32 only -- the counters are per
         # launch, so they do not depend on the step count)
         pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
         if args.dtype == "f32" and B == 64 and os.path.exists(pmc_file):
@@ -239,6 +240,7 @@ def main():
                        "global_batch": B * world, "parallelism": f"frames-dp{world}",
                        "lanes_per_gpu": lanes,
                        **({"rehearsal": f"{world} ranks share {n_dev} GPU(s), gloo"} if shared else {})},
+            **({"replay_only": True} if args.replay_only else {}),
             "roofline": roofline,
             "whole_net": {"mfma_frac": round(per_gpu * work["flops"] / (mfma_peak * 1e12), 4),
                           "hbm_frac_canonical": round(per_gpu * canon_bytes / (HBM_PEAK_GBS * 1e9), 4),

@@ -103,13 +103,16 @@ struct GemmEpilogue {
   // kStreamKCounters zeroed counters, private to the stream the GEMM runs on
   float* sk_ws = nullptr;
   unsigned* sk_cnt = nullptr;
+  // the launch shares the chip with another lane's kernels (two-lane schedule): tile choice then
+  // favours many small workgroups that interleave on a CU over few large ones (see pick_cfg)
+  int concurrent = 0;
 };
 constexpr int kStreamKWgs = 256;                                  // stream-K workgroups (one per CU)
 constexpr long long kStreamKFloats = 2ll * kStreamKWgs * 128 * 64;  // two partial tiles per workgroup, up to 128x64
 constexpr int kStreamKCounters = 256;
 constexpr long long kStreamKBytes = kStreamKFloats * 4 + kStreamKCounters * 4;
 
-const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype = DT_F32);
+const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype = DT_F32, bool concurrent = false);
 // a, w, c (and the (T) epilogue pointers) are `dtype` elements; lda/ldc in elements
 int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int m, int n, int k,
                    const GemmEpilogue& epi, hipStream_t stream, int dtype = DT_F32);

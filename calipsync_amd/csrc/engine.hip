@@ -286,6 +286,7 @@ struct Plan {
   // other lane's kernels already fill a launch's idle CUs and the split only adds traffic
   // (measured -1.1 % fp32 B=64, -1.9 % bf16 B=512).
   bool stream_k = false;
+  bool concurrent = false;            // another lane runs beside this one
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // audio source: either the NCHW windows tensor (`audio`) or, when win_feat is set, the whole
   // HuBERT feature array + per-frame indices, gathered on the device (infer_api.py:99-145)
@@ -316,7 +317,8 @@ struct Plan {
       epi.sk_ws = reinterpret_cast<float*>(ctx);
       epi.sk_cnt = reinterpret_cast<unsigned*>(ctx + kStreamKFloats * 4);
     }
-    r.run(tag.c_str(), pw_gemm_kernel_name((int)m, n, k, epi.sk_ws != nullptr, dt()), 2.0 * m * n * k, bytes,
+    epi.concurrent = concurrent ? 1 : 0;
+    r.run(tag.c_str(), pw_gemm_kernel_name((int)m, n, k, epi.sk_ws != nullptr, dt(), concurrent), 2.0 * m * n * k, bytes,
           [&] { return launch_pw_gemm(a, lda, w, c, ldc, (int)m, n, k, epi, r.s, dt()); });
   }
 
@@ -702,6 +704,7 @@ static int forward_impl(casync_handle h, const float* x, const float* a, const f
     Plan p{*h, Arena(), r, bl};
     p.lane = l;
     p.stream_k = lanes == 1;
+    p.concurrent = lanes > 1;
     p.ar.bind(ws, batch, dtype_size(h->dtype));
     p.ar.slice(b0);
     if (overlap) {
@@ -744,6 +747,7 @@ int casync_profile_forward(casync_handle h, const float* x, const float* a, floa
     Plan p{*h, Arena(), r, bl};
     p.lane = l;
     p.stream_k = lanes == 1;
+    p.concurrent = lanes > 1;
     p.ar.bind(ws, batch, dtype_size(h->dtype));
     p.ar.slice(b0);
     p.forward(x + (size_t)b0 * 6 * 160 * 160, a + (size_t)b0 * 32 * 32 * 32, out + (size_t)b0 * 3 * 160 * 160);

@@ -603,7 +603,7 @@ bool takes_ring(const TileCfg& t, long long tiles, int dtype) {
          ((dtype == DT_BF16 && glds_mode() >= 1) || (dtype == DT_F32 && glds_mode() >= 2));
 }
 
-int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullptr) {
+int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullptr, bool concurrent = false) {
   static const int forced = [] { const char* v = getenv("CASYNC_GEMM_CFG"); return v ? atoi(v) : -1; }();
   const int nk = k / (ROWB / dtype_size(dtype));
   if (use_sk) *use_sk = false;
@@ -619,10 +619,18 @@ int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullp
   // +600 is the worse operand reuse of small tiles.  Stream-K makes the last round fractional
   // and adds ~5 us (64x64) to ~10 us (128x64) of short-run start-up, parking and fix-up (priced
   // a little higher here so that it is only chosen where it clearly wins).
+  static const int conc_mode = [] { const char* e = getenv("CASYNC_GEMM_CONC"); return e && *e ? atoi(e) : 3; }();
+  static const int conc_tiles = [] { const char* e = getenv("CASYNC_GEMM_CONC_TILES"); return e && *e ? atoi(e) : 2048; }();
+  const long long t64 = (long long)((m + 63) / 64) * (n / 64);
   int best = -1;
   double best_cost = 0;
   for (const TileCfg& t : kTiles) {
     if (n % t.bn || t.id >= C64x32) continue;   // experimental configs: only when forced
+    if (concurrent && n % 64 == 0) {
+      if (conc_mode == 1 && t.id != C64x64) continue;
+      if (conc_mode == 2 && t.id == C128x128) continue;
+      if (conc_mode == 3 && t64 <= conc_tiles && t.id != C64x64) continue;
+    }
     const long long g = (long long)((m + t.bm - 1) / t.bm) * (n / t.bn);
     const double per_round = nk * (t.bm * t.bn + 600.0) / 8192.0;
     double cost = (double)((g + 255) / 256) * per_round;
@@ -642,10 +650,10 @@ int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullp
 }  // namespace
 
 // Name of the kernel instance launch_pw_gemm() will pick (as rocprofv3 prints it).
-const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype) {
+const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype, bool concurrent) {
   static thread_local char buf[64];
   const char* t = dtype == DT_BF16 ? "__bf16" : "float";
-  const int id = pick_cfg(m, n, k, stream_k, dtype);
+  const int id = pick_cfg(m, n, k, stream_k, dtype, nullptr, concurrent);
   const char* cfg;
   switch (id) {
     case C128x128: cfg = "128, 128, 2, 2"; break;
@@ -685,7 +693,7 @@ int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int 
                      (!epi.acc_out || ((uintptr_t)epi.acc_out % 16 == 0 && (uintptr_t)epi.acc_in % 16 == 0)),
                  "pw_gemm: residual pointers must be 16-B aligned");
   bool sk = false;
-  switch (pick_cfg(m, n, k, epi.sk_ws != nullptr, dtype, &sk)) {
+  switch (pick_cfg(m, n, k, epi.sk_ws != nullptr, dtype, &sk, epi.concurrent != 0)) {
     case C128x128: return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
     case C128x64: return launch_cfg<128, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
     case C64x64: return launch_cfg<64, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);

@@ -37,7 +37,7 @@ for k in sorted(set(fetch) | set(write)):
     out[k] = {"launches_sampled": n, "fetch_bytes_per_launch": round(2 * fk * 1024), "write_bytes_per_launch": round(wk * 1024),
               "hbm_bytes_per_launch": round((2 * fk + wk) * 1024)}
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of bench.py B=64 fp32, "
-                     "CASYNC_LANES=1 CASYNC_GEMM_STREAMK=0 CASYNC_OVERLAP=0; FETCH_SIZE x2 (gfx950), KB -> bytes",
+                     "--replay-only (the timed run's launches, serialised); FETCH_SIZE x2 (gfx950), KB -> bytes",
            "kernels": out}, open(sys.argv[3], "w"), indent=1)
 for k, v in out.items():
     print(f"{k:55s} n={v['launches_sampled']:4d}  fetch {v['fetch_bytes_per_launch'] / 1e6:9.2f} MB  write {v['write_bytes_per_launch'] / 1e6:9.2f} MB")
