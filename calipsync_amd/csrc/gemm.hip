@@ -563,9 +563,10 @@ template <int BM, int BN, int WM, int WN>
 int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, int n, int k,
                const GemmEpilogue& epi, hipStream_t stream, int dtype, bool use_sk) {
   // ring depth: 128x128 -> 3 stages (96 KB, one workgroup per CU), 128x64 -> 2 stages (48 KB, three
-  // per CU), 64x64 -> 3 stages (48 KB, three per CU).  Measured: one more co-resident workgroup
-  // beats one more stage of prefetch (+1.5 % fp32, +3.6 % bf16 end to end).
-  constexpr int NST = (BM + BN) >= 256 ? 3 : ((BM + BN) >= 192 ? 2 : 3);
+  // per CU), 64x64 -> 2 stages (32 KB, five per CU).  Measured every time: one more co-resident
+  // workgroup beats one more stage of prefetch (128x64: +1.5 % fp32, +3.6 % bf16 end to end;
+  // 64x64 two stages vs three: +0.8 % at B=64, +1.6 % at B=32 in the two-lane schedule).
+  constexpr int NST = (BM + BN) >= 256 ? 3 : 2;
   // The 128x128 ring leaves room for one workgroup per CU only: use it when the launch has at most
   // one tile per CU anyway (then its deeper pipeline wins), else the register-staged kernel with
   // two co-resident workgroups.  The smaller tiles always take the ring.
@@ -667,7 +668,7 @@ const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype, b
   const long long tiles = (long long)((m + tc.bm - 1) / tc.bm) * (n / tc.bn);
   if (takes_ring(tc, tiles, dtype))
     snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, %d>", t, cfg,
-             tc.bm + tc.bn >= 256 ? 3 : (tc.bm + tc.bn >= 192 ? 2 : 3));
+             tc.bm + tc.bn >= 256 ? 3 : 2);
   else
     snprintf(buf, sizeof(buf), "pw_gemm_kernel<%s, %s>", t, cfg);
   return buf;
