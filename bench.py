@@ -45,6 +45,9 @@ def parse():
                     help="frames per GPU per step (default: 64 for f32 = configs[1], 512 for bf16 = configs[2])")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="engine activation storage: f32 = parity path (default), bf16 = BASELINE configs[2]")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: a FIXED number of frames per step split over the ranks "
+                         "(SURVEY 8d: 4096); default 0 = weak scaling, --batch frames per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--kernel-table", action="store_true", help="print the per-launch table to stderr")
@@ -138,6 +141,10 @@ def main():
 
     # ---- inputs: this rank's contiguous shard of the global synthetic batch, resident in HBM
     B = args.batch
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} must be a multiple of the {world} ranks")
+        B = args.global_batch // world
     start, count = shard_range(B * world, rank, world)
     x_np, a_np = recipe.make_inputs_range(start, count)
     x, a = torch.from_numpy(x_np).to(dev), torch.from_numpy(a_np).to(dev)
@@ -230,7 +237,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.global_batch else "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.dtype == "f32" else "bf16 (fp32 accumulate; NOT the parity path)",
             "data": "synthetic",
