@@ -58,6 +58,30 @@ def test_pw_gemm_stream_k_remainder(lib, m, n, k):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
 
 
+def test_pw_gemm_stream_k_random_shapes_match_plain_tiles(lib, monkeypatch):
+    """Stress: 48 random shapes, stream-K on vs off (plain tiles) on the same operands -- equal to fp32
+    reassociation, and the stream-K result repeats bit for bit (no arrival-order dependence)."""
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for _ in range(48):
+        m = int(rng.integers(1, 30000))
+        n = int(rng.integers(1, 37)) * 64
+        k = int(rng.integers(8, 73)) * 32
+        g = torch.Generator().manual_seed(m * 31 + n + k)
+        ad = torch.randn(m, k, generator=g).to(dev())
+        wd = (torch.randn(n, k, generator=g) / k ** 0.5).to(dev())
+        bd = torch.randn(n, generator=g).to(dev())
+        outs = []
+        for sk in ("1", "1", "0"):
+            monkeypatch.setenv("CASYNC_GEMM_STREAMK", sk)
+            c = torch.full((m, n), float("nan"), device=dev())
+            ok(lib.casync_op_pw_gemm(ptr(ad), k, ptr(wd), ptr(bd), ptr(c), n, m, n, k, 1, 0, 0, 0, 0, 0, 0, 0, stream()))
+            outs.append(c)
+        assert torch.equal(outs[0], outs[1]), (m, n, k)
+        worst = max(worst, rel_err(outs[0], outs[2]))
+    assert worst < 5e-6, worst
+
+
 def test_pw_gemm_epilogue_and_strides(lib):
     """lda/ldc slices of wider buffers + pre-residual (scaled) + post-residual + affine."""
     g = torch.Generator().manual_seed(3)
