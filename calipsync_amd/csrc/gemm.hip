@@ -633,7 +633,9 @@ int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullp
       if (conc_mode == 3 && t64 <= conc_tiles && t.id != C64x64) continue;
     }
     const long long g = (long long)((m + t.bm - 1) / t.bm) * (n / t.bn);
-    const double per_round = nk * (t.bm * t.bn + 600.0) / 8192.0;
+    // bf16 tiles are data-movement / latency bound (the MFMAs are 8x cheaper), so the fixed cost of a
+    // tile weighs ~10x more against its area: larger tiles win (all-128x128 +3.4 % at B=512)
+    const double per_round = nk * (t.bm * t.bn + (dtype == DT_BF16 ? 6000.0 : 600.0)) / 8192.0;
     double cost = (double)((g + 255) / 256) * per_round;
     bool sk_better = false;
     if (takes_ring(t, g, dtype) && stream_k_split(g, nk, t.bm * t.bn, stream_k).wgs) {
