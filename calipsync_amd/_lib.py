@@ -62,6 +62,8 @@ _PROTOS = {
     "casync_op_cross_attention": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int,
                                             c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int,
                                             C.c_void_p]),
+    "casync_op_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "casync_op_crop_to_input": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.c_void_p]),
     "casync_op_pred_to_u8": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_void_p]),
     "casync_op_nchw_to_nhwc": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -106,6 +106,10 @@ struct GemmEpilogue {
   // the launch shares the chip with another lane's kernels (two-lane schedule): tile choice then
   // favours many small workgroups that interleave on a CU over few large ones (see pick_cfg)
   int concurrent = 0;
+  // implicit-GEMM 3x3 convolution (conv_on): A is the NHWC input [B,H,W,C]; row m of the GEMM is output
+  // pixel (b, oy, ox), column k = (ky*3 + kx)*C + c reads in[b, oy*stride+ky-pad, ox*stride+kx-pad, c]
+  // (zero outside the image); W is [N][(ky,kx,c)].  K = 9*C, C a multiple of the 128-B k-tile.
+  int conv_on = 0, conv_h = 0, conv_w = 0, conv_c = 0, conv_ho = 0, conv_wo = 0, conv_stride = 0, conv_pad = 0;
 };
 constexpr int kStreamKWgs = 256;                                  // stream-K workgroups (one per CU)
 constexpr long long kStreamKFloats = 2ll * kStreamKWgs * 128 * 64;  // two partial tiles per workgroup, up to 128x64
@@ -116,6 +120,15 @@ const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype = 
 // a, w, c (and the (T) epilogue pointers) are `dtype` elements; lda/ldc in elements
 int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int m, int n, int k,
                    const GemmEpilogue& epi, hipStream_t stream, int dtype = DT_F32);
+
+// dense 3x3 convolution + bias (+ LeakyReLU if epi.act) as an implicit GEMM on the ring kernel: no im2col
+// buffer, the taps are gathered by the LDS-DMA loads themselves.  in: [B,H,W,cin] contiguous NHWC,
+// w: [cout][(ky,kx,cin)], out: [B*Ho*Wo, ldc].
+int launch_conv3x3_gemm(const void* in, const void* w, void* out, int ldc, int batch, int h, int wdt, int cin,
+                        int cout, int stride, int pad, const GemmEpilogue& epi, hipStream_t stream,
+                        int dtype = DT_F32);
+const char* conv3x3_gemm_kernel_name(int batch, int h, int wdt, int cin, int cout, int stride, int pad,
+                                     int dtype = DT_F32, bool concurrent = false);
 
 // ---- other operators -------------------------------------------------------
 int launch_dw3x3(const void* in, const float* w, const float* bias, void* out, int batch, int h,

@@ -322,6 +322,34 @@ struct Plan {
           [&] { return launch_pw_gemm(a, lda, w, c, ldc, (int)m, n, k, epi, r.s, dt()); });
   }
 
+  // Dense 3x3 conv + bias + LReLU (audio conv3 / conv5, module/unet.py:161-168) as an implicit GEMM:
+  // the ring kernel gathers the taps itself (CASYNC_CONV_IM2COL=1 restores im2col + plain GEMM).
+  void conv3x3(const std::string& tag, Ptr in, const std::string& wname, Ptr out, int hw, int cin, int cout,
+               int stride, int pad) {
+    const int ho = (hw + 2 * pad - 3) / stride + 1;
+    const long long m = (long long)B * ho * ho;
+    GemmEpilogue ep;
+    ep.act = 1;
+    if (env_int("CASYNC_CONV_IM2COL", 0)) {
+      r.run((tag + ".im2col").c_str(), kname("im2col3x3_kernel").c_str(), 0,
+            dtype_size(dt()) * (double)B * ((double)hw * hw * cin + (double)ho * ho * 9 * cin),
+            [&] { return launch_im2col3x3(in, ar[Arena::IM], B, hw, hw, cin, stride, pad, r.s, dt()); });
+      gemm(tag, ar[Arena::IM], 9 * cin, wname, out, cout, m, cout, 9 * cin, ep);
+      return;
+    }
+    ep.bias = e.W(wname.substr(0, wname.size() - 1) + "b");
+    ep.concurrent = concurrent ? 1 : 0;
+    if (char* ctx = stream_k ? e.sk_ctx(lane, aux && r.s == aux ? 1 : 0) : nullptr) {
+      ep.sk_ws = reinterpret_cast<float*>(ctx);
+      ep.sk_cnt = reinterpret_cast<unsigned*>(ctx + kStreamKFloats * 4);
+    }
+    const double es = dtype_size(dt());
+    r.run(tag.c_str(), conv3x3_gemm_kernel_name(B, hw, hw, cin, cout, stride, pad, dt(), concurrent),
+          2.0 * m * cout * 9 * cin, es * ((double)B * hw * hw * cin + (double)m * cout + 9.0 * cin * cout), [&] {
+      return launch_conv3x3_gemm(in, e.WG(wname), out, cout, B, hw, hw, cin, cout, stride, pad, ep, r.s, dt());
+    });
+  }
+
   // One inverted-residual block.  in: [B*hw_in^2, cin] (ld_in); out: [B*hw_out^2, cout] (ld_out).
   void ir(const IR& b, Ptr in, int ld_in, Ptr out, int ld_out, Ptr e1, Ptr e2,
           const GemmEpilogue* extra = nullptr) {
@@ -382,23 +410,9 @@ struct Plan {
             [&] { return launch_nchw_to_nhwc(audio, ar[A::A0], B, 32, 1024, r.s, dt()); });
     ir(kAudio[0], ar[A::A0], 32, ar[A::AC1], 64, AE1, AE2);
     ir(kAudio[1], ar[A::AC1], 64, ar[A::AC2], 128, AE1, AE2);
-    r.run("audio.conv3.im2col", kname("im2col3x3_kernel").c_str(), 0, dtype_size(dt()) * (double)B * (131072 + 256 * 1152), [&] {
-      return launch_im2col3x3(ar[A::AC2], ar[A::IM], B, 32, 32, 128, 2, 1, r.s, dt());
-    });
-    {
-      GemmEpilogue ep;
-      ep.act = 1;
-      gemm("audio.conv3", ar[A::IM], 1152, "audio_model.conv3.w", ar[A::AC3], 256, (long long)B * 256, 256, 1152, ep);
-    }
+    conv3x3("audio.conv3", ar[A::AC2], "audio_model.conv3.w", ar[A::AC3], 32, 128, 256, 2, 1);
     ir(kAudio[2], ar[A::AC3], 256, ar[A::AC4], 256, AE1, AE2);
-    r.run("audio.conv5.im2col", kname("im2col3x3_kernel").c_str(), 0, dtype_size(dt()) * (double)B * (65536 + 100 * 2304), [&] {
-      return launch_im2col3x3(ar[A::AC4], ar[A::IM], B, 16, 16, 256, 2, 3, r.s, dt());
-    });
-    {
-      GemmEpilogue ep;
-      ep.act = 1;
-      gemm("audio.conv5", ar[A::IM], 2304, "audio_model.conv5.w", ar[A::AC5], 512, (long long)B * 100, 512, 2304, ep);
-    }
+    conv3x3("audio.conv5", ar[A::AC4], "audio_model.conv5.w", ar[A::AC5], 16, 256, 512, 2, 3);
     ir(kAudio[3], ar[A::AC5], 512, ar[A::AC6], 512, AE1, AE2);
     {
       GemmEpilogue bn7;  // relu7(bn7(x + conv(x))) fused behind conv7's residual add
@@ -830,6 +844,13 @@ int casync_op_pw_gemm(const void* a, int lda, const void* w, const float* bias, 
     e.sk_cnt = reinterpret_cast<unsigned*>(scratch[dev] + kStreamKFloats * 4);
   }
   return launch_pw_gemm(a, lda, w, c, ldc, m, n, k, e, (hipStream_t)stream, g_op_dtype);
+}
+int casync_op_conv3x3(const void* in, const void* w, const float* bias, void* out, int batch, int h, int wdt,
+                      int cin, int cout, int stride, int pad, int act, casync_stream stream) {
+  GemmEpilogue e;
+  e.bias = bias;
+  e.act = act;
+  return launch_conv3x3_gemm(in, w, out, cout, batch, h, wdt, cin, cout, stride, pad, e, (hipStream_t)stream, g_op_dtype);
 }
 int casync_op_dw3x3(const void* in, const float* w, const float* bias, void* out, int batch, int h,
                     int wdt, int c, int stride, casync_stream stream) {

@@ -298,7 +298,10 @@ inline StreamKSplit stream_k_split(long long tiles, int nk, int tile_floats, boo
 // =====================================================================================
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST>
+// 256 B of zeros: where the implicit-GEMM convolution points its LDS-DMA loads for taps outside the image
+__device__ __attribute__((aligned(256))) float g_zero_page[64];
+
+template <typename T, int BM, int BN, int WM, int WN, int NST, bool CONV = false>
 __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__ A, int lda,
                                                            const T* __restrict__ W, T* __restrict__ C,
                                                            int ldc, int M, int N, int K, int n_ntiles,
@@ -347,6 +350,7 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
   auto run_k = [&](int k0, int cnt) {
     // this lane's source pointer for each of the wave's LPT instructions (k-tile k0)
     const T* src[LPT];
+    int tapmask[CONV ? LPT : 1];   // CONV: which of the 9 taps of this row's pixel are inside the image
 #pragma unroll
     for (int j = 0; j < LPT; ++j) {
       const int r = (j * 4 + wave) * 8 + lrow8;             // row inside the stage: [0,BM) = A, [BM,ROWS) = W
@@ -354,18 +358,50 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
       if (r < BM) {
         int row = m0 + r;
         row = row < M ? row : M - 1;
-        src[j] = A + (size_t)row * lda + cs * E16 + (size_t)k0 * BK;
+        if constexpr (CONV) {
+          // row = output pixel (b, oy, ox); src = its tap (0,0) -- possibly outside the buffer, only
+          // dereferenced for taps the mask marks valid
+          const int hw = epi.conv_ho * epi.conv_wo;
+          const int b = row / hw, rem = row - b * hw;
+          const int oy = rem / epi.conv_wo, ox = rem - oy * epi.conv_wo;
+          const int iy0 = oy * epi.conv_stride - epi.conv_pad, ix0 = ox * epi.conv_stride - epi.conv_pad;
+          src[j] = A + (((long long)b * epi.conv_h + iy0) * epi.conv_w + ix0) * (long long)epi.conv_c + cs * E16;
+          int mk = 0;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+            mk |= (iy >= 0 && iy < epi.conv_h && ix >= 0 && ix < epi.conv_w) ? 1 << t : 0;
+          }
+          tapmask[j] = mk;
+        } else {
+          src[j] = A + (size_t)row * lda + cs * E16 + (size_t)k0 * BK;
+        }
       } else {
         src[j] = W + (size_t)(n0 + r - BM) * K + cs * E16 + (size_t)k0 * BK;
       }
     }
     auto issue = [&](int kt) {
       char* st = ring + (kt % NST) * STAGE;
+      [[maybe_unused]] int tap = 0, tap_off = 0;
+      if constexpr (CONV) {   // k-tile -> (tap, channel offset): C / BK k-tiles per tap
+        const int kpt = epi.conv_c / BK, kg = k0 + kt;
+        tap = kg / kpt;
+        tap_off = ((tap / 3) * epi.conv_w + tap % 3) * epi.conv_c + (kg - tap * kpt) * BK;
+      }
 #pragma unroll
-      for (int j = 0; j < LPT; ++j)
-        __builtin_amdgcn_global_load_lds(
-            (const void __attribute__((address_space(1)))*)(src[j] + (size_t)kt * BK),
-            (void __attribute__((address_space(3)))*)(st + (j * 4 + wave) * 8 * ROWB), 16, 0, 0);
+      for (int j = 0; j < LPT; ++j) {
+        const T* p;
+        if (CONV && j < BM / 32) {   // rows of the A part (compile-time per j: r < BM <=> j < BM/32)
+          const int r = (j * 4 + wave) * 8 + lrow8;
+          p = (tapmask[CONV ? j : 0] >> tap) & 1 ? src[j] + tap_off
+                                                 : reinterpret_cast<const T*>(g_zero_page) + (lcol ^ ((r >> 1) & 7)) * E16;
+        } else {
+          p = src[j] + (size_t)kt * BK;
+        }
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)p,
+                                         (void __attribute__((address_space(3)))*)(st + (j * 4 + wave) * 8 * ROWB),
+                                         16, 0, 0);
+      }
     };
     zero_acc();
 #pragma unroll
@@ -504,12 +540,12 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST>
+template <typename T, int BM, int BN, int WM, int WN, int NST, bool CONV = false>
 int launch_glds_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, int k,
                   const GemmEpilogue& epi, hipStream_t stream, bool use_sk) {
   constexpr size_t lds = (size_t)NST * (BM + BN) * ROWB;
   static bool attr_set = false;
-  auto kern = pw_gemm_glds_kernel<T, BM, BN, WM, WN, NST>;
+  auto kern = pw_gemm_glds_kernel<T, BM, BN, WM, WN, NST, CONV>;
   if (!attr_set) {
     CASYNC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -704,4 +740,55 @@ int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int 
     case C64x64W2: return launch_cfg<64, 64, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
     default: return launch_cfg<128, 32, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
   }
+}
+
+// ---------------------------------------------------------------- dense 3x3 as an implicit GEMM
+namespace {
+template <typename T>
+int launch_conv_t(const T* in, const T* w, T* out, int ldc, int m, int n, int k, const GemmEpilogue& epi,
+                  hipStream_t stream, int dtype) {
+  bool sk = false;
+  const int cfg = pick_cfg(m, n, k, epi.sk_ws != nullptr, dtype, &sk, epi.concurrent != 0);
+  // the ring kernel's two 48-KB-class tiles; the A "leading dimension" is unused (rows are gathered)
+  if (cfg == C64x64 || n % 64 || m <= 4096)
+    return launch_glds_t<T, 64, 64, 2, 2, 2, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C64x64);
+  return launch_glds_t<T, 128, 64, 2, 2, 2, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C128x64);
+}
+}  // namespace
+
+const char* conv3x3_gemm_kernel_name(int batch, int h, int wdt, int cin, int cout, int stride, int pad, int dtype,
+                                     bool concurrent) {
+  static thread_local char buf[64];
+  const int ho = (h + 2 * pad - 3) / stride + 1, wo = (wdt + 2 * pad - 3) / stride + 1;
+  const int m = batch * ho * wo;
+  const int cfg = pick_cfg(m, cout, 9 * cin, false, dtype, nullptr, concurrent);
+  const bool small = cfg == C64x64 || cout % 64 || m <= 4096;
+  snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, 2, 2, 2, true>", dtype == DT_BF16 ? "__bf16" : "float",
+           small ? "64, 64" : "128, 64");
+  return buf;
+}
+
+int launch_conv3x3_gemm(const void* in, const void* w, void* out, int ldc, int batch, int h, int wdt, int cin,
+                        int cout, int stride, int pad, const GemmEpilogue& epi_in, hipStream_t stream, int dtype) {
+  const int bk = ROWB / dtype_size(dtype), e16 = 16 / dtype_size(dtype);
+  CASYNC_REQUIRE(in && w && out && batch > 0, "conv3x3: bad args");
+  CASYNC_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "conv3x3: dtype %d", dtype);
+  CASYNC_REQUIRE(cin % bk == 0, "conv3x3: cin=%d must be a multiple of %d", cin, bk);
+  CASYNC_REQUIRE(cout % 64 == 0, "conv3x3: cout=%d must be a multiple of 64", cout);
+  CASYNC_REQUIRE(stride >= 1 && pad >= 0 && h + 2 * pad >= 3 && wdt + 2 * pad >= 3, "conv3x3: geometry");
+  CASYNC_REQUIRE(ldc >= cout && ldc % e16 == 0, "conv3x3: ldc=%d", ldc);
+  CASYNC_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                 "conv3x3: in/w/out must be 16-B aligned");
+  GemmEpilogue epi = epi_in;
+  epi.conv_on = 1;
+  epi.conv_h = h; epi.conv_w = wdt; epi.conv_c = cin; epi.conv_stride = stride; epi.conv_pad = pad;
+  epi.conv_ho = (h + 2 * pad - 3) / stride + 1;
+  epi.conv_wo = (wdt + 2 * pad - 3) / stride + 1;
+  const long long m = (long long)batch * epi.conv_ho * epi.conv_wo;
+  CASYNC_REQUIRE(m < (1ll << 31), "conv3x3: too many output pixels");
+  if (dtype == DT_BF16)
+    return launch_conv_t<bf16_t>(static_cast<const bf16_t*>(in), static_cast<const bf16_t*>(w), static_cast<bf16_t*>(out),
+                                 ldc, (int)m, cout, 9 * cin, epi, stream, dtype);
+  return launch_conv_t<float>(static_cast<const float*>(in), static_cast<const float*>(w), static_cast<float*>(out), ldc,
+                              (int)m, cout, 9 * cin, epi, stream, dtype);
 }

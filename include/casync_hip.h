@@ -129,6 +129,12 @@ int casync_op_pw_gemm(const void* a, int lda, const void* w, const float* bias,
                       const void* pre_res, int ld_pre, const float* pre_scale,
                       const void* post_res, int ld_post,
                       const float* aff_s, const float* aff_t, casync_stream stream);
+/* nn.Conv2d(k=3, bias) + folded BN + LeakyReLU of the audio encoder (conv3: stride 2 pad 1, conv5: stride 2
+ * pad 3; module/unet.py:161-168) as an implicit GEMM: in [B,H,W,cin] NHWC, w [cout][(ky,kx,cin)],
+ * out [B,Ho,Wo,cout].  cin % (128 B / elem) == 0, cout % 64 == 0. */
+int casync_op_conv3x3(const void* in, const void* w, const float* bias, void* out, int batch, int h, int w_,
+                      int cin, int cout, int stride, int pad, int act, casync_stream stream);
+
 /* Depthwise 3x3, pad 1, stride 1|2, + bias + LeakyReLU on NHWC.
  * Replaces nn.Conv2d(groups=C,k=3)+BN+LeakyReLU (module/unet.py:21-30).
  * w is tap-major [9][C].                                                    */

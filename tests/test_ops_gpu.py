@@ -148,6 +148,25 @@ def test_dense3x3_via_im2col(lib, h, c, stride, padv, cout):
     assert rel_err(nchw(out.view(b, ho, ho, cout)), ref) < 3e-6
 
 
+@pytest.mark.parametrize("b,h,w,c,stride,padv,cout", [(2, 32, 32, 128, 2, 1, 256), (2, 16, 16, 256, 2, 3, 512),
+                                                        (70, 16, 16, 256, 2, 3, 512), (3, 9, 13, 64, 1, 1, 64),
+                                                        (1, 7, 5, 32, 1, 0, 128), (5, 11, 11, 32, 2, 2, 64)])
+def test_conv3x3_implicit_gemm(lib, b, h, w, c, stride, padv, cout):
+    """Dense 3x3 (audio conv3: pad 1, conv5: pad 3, 16 -> 10) with the taps gathered by the GEMM's own
+    loads: same result as F.conv2d, including ragged sizes, pad 0 and stream-K-able shapes."""
+    g = torch.Generator().manual_seed(h * 31 + c)
+    x = torch.randn(b, c, h, w, generator=g)
+    wt = torch.randn(cout, c, 3, 3, generator=g) / (3 * c ** 0.5)
+    bias = torch.randn(cout, generator=g)
+    ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), bias.double(), stride, padv), 0.01).float()
+    ho, wo = ref.shape[2], ref.shape[3]
+    xd, bd = nhwc(x), bias.to(dev())
+    wp = wt.permute(0, 2, 3, 1).reshape(cout, 9 * c).contiguous().to(dev())
+    out = torch.full((b, ho, wo, cout), float("nan"), device=dev())
+    ok(lib.casync_op_conv3x3(ptr(xd), ptr(wp), ptr(bd), ptr(out), b, h, w, c, cout, stride, padv, 1, stream()))
+    assert rel_err(nchw(out), ref) < 3e-6
+
+
 @pytest.mark.parametrize("h,c", [(10, 256), (20, 128), (40, 64), (80, 32), (3, 4)])
 def test_upsample2x_align_corners(lib, h, c):
     x = torch.randn(2, c, h, h, generator=torch.Generator().manual_seed(h))
