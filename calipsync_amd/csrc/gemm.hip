@@ -705,7 +705,7 @@ const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype, b
   const TileCfg& tc = kTiles[id];
   const long long tiles = (long long)((m + tc.bm - 1) / tc.bm) * (n / tc.bn);
   if (takes_ring(tc, tiles, dtype))
-    snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, %d>", t, cfg,
+    snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, %d, false>", t, cfg,
              tc.bm + tc.bn >= 256 ? 3 : 2);
   else
     snprintf(buf, sizeof(buf), "pw_gemm_kernel<%s, %s>", t, cfg);
