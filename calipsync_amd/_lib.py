@@ -17,7 +17,7 @@ c_i64 = C.c_int64
 
 
 class KernelTime(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("kernel", C.c_char * 48), ("ms", C.c_float), ("flops", C.c_double),
+    _fields_ = [("name", C.c_char * 48), ("kernel", C.c_char * 64), ("ms", C.c_float), ("flops", C.c_double),
                 ("bytes", C.c_double)]
 
 

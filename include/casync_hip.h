@@ -104,7 +104,7 @@ int64_t casync_tap(casync_handle h, const char* name, int batch, void* workspace
  * `stream`; synchronises).  Writes up to `cap` entries; returns the count.  */
 typedef struct {
   char  name[48];     /* plan step, e.g. "up4.conv.double_conv.0.fused"      */
-  char  kernel[48];   /* HIP kernel instance as rocprofv3 names it           */
+  char  kernel[64];   /* HIP kernel instance as rocprofv3 names it           */
   float ms;
   double flops;       /* algorithmic flops of this launch                   */
   double bytes;       /* algorithmic bytes (inputs read once + outputs)     */
