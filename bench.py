@@ -245,7 +245,7 @@ def main():
                                    f"({'BASELINE configs[1]' if args.dtype == 'f32' else 'bf16 engine, BASELINE configs[2] family'}); "
                                    "frames sharded, weights broadcast once",
                        "global_batch": B * world, "parallelism": f"frames-dp{world}",
-                       "lanes_per_gpu": lanes,
+                       "lanes_per_gpu": lanes if B >= 16 * lanes else 1,   # the engine runs small batches as one lane
                        **({"rehearsal": f"{world} ranks share {n_dev} GPU(s), gloo"} if shared else {})},
             **({"replay_only": True} if args.replay_only else {}),
             "roofline": roofline,
