@@ -9,10 +9,13 @@ synthetic crops U(0,1) + random HuBERT windows N(0,1) (the reference's own self-
 shapes, image_infer_v1/models/unet.py:342-347), golden-recipe weights.  Inputs are
 resident in HBM before the timed region; outputs stay on the device.
 
-N > 1: one process per GPU (torch.distributed, backend "nccl" == RCCL).  Frames are
-independent, so the batch is sharded with no data-path collective ("weak" scaling: 64
-frames per GPU); the only collective is ONE broadcast of the packed, BN-folded weight
-buffer from rank 0 at start-up.
+N > 1: one process per GPU (torch.distributed, backend "nccl" == RCCL).  Either the driver starts
+the ranks (``python -m torch.distributed.run ... bench.py --gpus N``: RANK/WORLD_SIZE in the
+environment) or ``python bench.py --gpus N`` starts them itself, as fresh child processes, BEFORE the
+parent touches the GPU.  Frames are independent, so the batch is sharded with no data-path
+collective ("weak" scaling: 64 frames per GPU); the only collective is ONE broadcast of the packed,
+BN-folded weight buffer from rank 0 at start-up.  At N > 1 the line also carries the
+BASELINE configs[3] split (4096 frames over the ranks) beside the weak point.
 
 Prints one JSON line (rank 0) with the whole-job frames/sec, the roofline of the dominant
 kernel (live HIP-event timing) and, at N=1, the CPU oracle timed on the host cores.
@@ -22,18 +25,19 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: f32-input MFMA == f32 vector peak
+MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: f32-input MFMA == f32 vector peak (155.4 measured here,
+                            # profiles/r2_mfma_clock.txt)
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
+PROFILE_TAG = "r2"          # profiles/<tag>_pmc_traffic.json, <tag>_mfma_busy.json feed roofline.traffic / mfma_busy
 
 
 def parse():
@@ -46,14 +50,19 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="engine activation storage: f32 = parity path (default), bf16 = BASELINE configs[2]")
     ap.add_argument("--global-batch", type=int, default=0,
-                    help="strong scaling: a FIXED number of frames per step split over the ranks "
+                    help="strong scaling as the headline: a FIXED number of frames per step split over the ranks "
                          "(SURVEY 8d: 4096); default 0 = weak scaling, --batch frames per GPU")
+    ap.add_argument("--strong-frames", type=int, default=4096,
+                    help="N > 1 only: frames of the configs[3] split timed beside the weak point (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU-oracle leg")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-launch table to stderr")
     ap.add_argument("--replay-only", action="store_true",
                     help="skip the timed region; run --steps isolated replays (the mode rocprofv3 / PMC passes "
                          "are collected in, so their per-kernel figures match the roofline block)")
+    ap.add_argument("--e2e", action="store_true",
+                    help="also time the device frame loop (process_batch: crop+resize -> forward -> paste-back "
+                         "blend on synthetic 1080p frames, one D2H per batch) and report it in config.e2e")
     return ap.parse_args()
 
 
@@ -75,39 +84,85 @@ def host_cores() -> int:
     return min(n, 16)
 
 
+def launch_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N fresh child processes (one rank per GPU)
+    with the torch.distributed environment, relay rank 0's JSON line, fail if any rank fails.  Nothing in
+    this parent process has touched the GPU (no torch import even), so nothing is re-executed from a
+    process that initialised HIP."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if out:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def cpu_baseline(sd_np, seconds: float):
-    """The CPU oracle (a port of the reference's forward, torch-CPU fp32) on the host cores."""
+    """The CPU oracle (a port of the reference's forward, torch-CPU fp32) on the host cores, at
+    B in {1, 8, 64}: median of the timed forwards per batch size, the B=64
+    figure (the GPU line's own batch) is `value`.  Bounded: ~`seconds` of CPU work in all."""
+    import torch
     from calipsync_amd import recipe
     from oracle import unet_oracle
     cores = host_cores()
     torch.set_num_threads(cores)
     sd = unet_oracle.to_torch(sd_np)
-    b = 8
-    x, a = recipe.make_inputs(b)
-    xt, at = torch.from_numpy(x), torch.from_numpy(a)
-    unet_oracle.forward(sd, xt, at)                      # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        unet_oracle.forward(sd, xt, at)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 50:
-            break
-    return {"value": round(n * b / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} forwards of batch {b} (same weights/input recipe), torch-CPU fp32, {dt:.1f} s"}
+    by_batch, spent = {}, 0.0
+    for b, reps in ((1, 10), (8, 5), (64, 3)):
+        x, a = recipe.make_inputs(b)
+        xt, at = torch.from_numpy(x), torch.from_numpy(a)
+        t0 = time.perf_counter()
+        unet_oracle.forward(sd, xt, at)                      # warm-up
+        warm = time.perf_counter() - t0
+        if b == 64 and spent + warm * (1 + reps) > 1.6 * seconds:
+            reps = 1
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            unet_oracle.forward(sd, xt, at)
+            times.append(time.perf_counter() - t0)
+        spent += warm + sum(times)
+        med = sorted(times)[len(times) // 2]
+        by_batch[str(b)] = {"frames_per_s": round(b / med, 2), "ms_per_forward": round(1e3 * med, 1), "timed_forwards": reps}
+    return {"value": by_batch["64"]["frames_per_s"], "unit": "frames/s", "cores": cores, "kind": "port",
+            "by_batch": by_batch,
+            "sample": f"torch-CPU fp32 oracle, same weights/input recipe, median forward at B=1/8/64 "
+                      f"({by_batch['1']['timed_forwards']}/{by_batch['8']['timed_forwards']}/{by_batch['64']['timed_forwards']} "
+                      f"timed after one warm-up each), {spent:.1f} s of CPU work; value = the B=64 figure"}
+
+
+def load_profile_json(name):
+    path = os.path.join(REPO, "profiles", f"{PROFILE_TAG}_{name}.json")
+    return json.load(open(path)) if os.path.exists(path) else None
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))       # before torch / HIP are even imported
+
+    import numpy as np  # noqa: F401
+    import torch
     if args.batch <= 0:
         args.batch = 64 if args.dtype == "f32" else 512
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // max(1, world)))   # N ranks x default threads oversubscribes
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path to benchmark")
     # one rank per GPU.  Rehearsal hook: on a box with fewer GPUs than ranks (the 1-GPU dev box)
@@ -120,14 +175,16 @@ def main():
     dev = torch.device("cuda", dev_index)
 
     import torch.distributed as dist
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if shared else "nccl"
         if shared:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from calipsync_amd import arch, recipe, _lib
+    from calipsync_amd import arch, recipe
     from calipsync_amd.unet import Model
     from calipsync_amd.sharding import broadcast_packed_weights, shard_range
 
@@ -155,6 +212,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    def max_over_ranks(seconds: float) -> float:
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], device="cpu" if shared else dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         out = net(x, a)
     sync()
@@ -162,20 +226,46 @@ def main():
     for _ in range(1 if args.replay_only else args.steps):
         out = net(x, a)
     sync()
-    dt = (time.perf_counter() - t0) * (args.steps if args.replay_only else 1)
-    if world > 1:
-        t = torch.tensor([dt], device="cpu" if shared else dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks((time.perf_counter() - t0) * (args.steps if args.replay_only else 1))
     assert torch.isfinite(out).all()
+
+    # ---- N > 1: BASELINE configs[3] beside the weak point -- a fixed 4096-frame job split over the
+    #      ranks, each rank walking its contiguous shard in chunks of <= 512 frames (the per-GPU size
+    #      configs[3] names; one arena serves every chunk).  Same timing contract: barrier + sync on
+    #      both sides, max over ranks.  Inputs are the weak leg's frames tiled (timing is data-blind).
+    strong = None
+    if world > 1 and args.strong_frames and not args.global_batch and not args.replay_only:
+        per_rank = shard_range(args.strong_frames, rank, world)[1]
+        chunk = min(512, max(1, per_rank))
+        reps = (chunk + x.shape[0] - 1) // x.shape[0]
+        xc, ac = x.repeat(reps, 1, 1, 1)[:chunk].contiguous(), a.repeat(reps, 1, 1, 1)[:chunk].contiguous()
+        n_full, tail = divmod(per_rank, chunk)
+
+        def strong_step():
+            for _ in range(n_full):
+                net(xc, ac)
+            if tail:
+                net(xc[:tail], ac[:tail])
+        strong_step()
+        sync()
+        s_steps = max(2, args.steps // 4)
+        t0 = time.perf_counter()
+        for _ in range(s_steps):
+            strong_step()
+        sync()
+        sdt = max_over_ranks(time.perf_counter() - t0)
+        strong = {"global_batch": args.strong_frames, "frames_per_gpu": per_rank, "chunk": chunk, "steps": s_steps,
+                  "value": round(args.strong_frames * s_steps / sdt, 1), "unit": "frames/s",
+                  "ms_per_step": round(1e3 * sdt / s_steps, 3), "scaling": "strong"}
 
     # ---- per-kernel timing with HIP events on the launch stream (rank 0)
     result = None
-    lanes = int(os.environ.get("CASYNC_LANES", "2"))
+    lanes = net.get_option("lanes")
+    trunk_lanes = net.get_option("trunk_lanes")
     if rank == 0:
         per = {}
         reps = args.steps if args.replay_only else 3
-        # The timed region overlaps `lanes` sub-batch lanes (and the audio stream) on the GPU, so
+        # The timed region overlaps the sub-batch lanes (and the audio streams) on the GPU, so
         # per-kernel durations there are not separable.  The roofline pass replays the SAME launches
         # (same lanes, hence the same kernels, tile choices and grids) serialised on one stream with
         # an event pair around each (casync_profile_forward).
@@ -197,6 +287,7 @@ def main():
         gbs = dom["bytes"] / dom["ms"] / 1e6
         mfma_peak = MFMA_F32_PEAK_TF if args.dtype == "f32" else MFMA_BF16_PEAK_TF
         mfma_bound = dom_name.startswith(("pw_gemm", "ir_fused")) and tf / mfma_peak >= gbs / HBM_PEAK_GBS
+        tag = f"{PROFILE_TAG}_{'f32_b64' if args.dtype == 'f32' else 'bf16_b512'}"
         roofline = {
             "kernel": dom_name,
             "bound": "mfma" if mfma_bound else "hbm",
@@ -206,28 +297,32 @@ def main():
             "frac": round((tf / mfma_peak) if mfma_bound else (gbs / HBM_PEAK_GBS), 4),
             "traffic": None,
             "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["n"]),
+            "algorithmic_gflop_per_launch": round(dom["flops"] / dom["n"] / 1e9, 3),
             "launches_per_step": dom["n"] // reps,
             "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
             "share_of_step": round(dom["ms"] / sum(c["ms"] for c in per.values()), 3),
             "measured": "HIP events around every launch; the timed run's own launches (same lanes, tiles, grids) "
-                        "serialised on one stream; profiles/r1_final_kernel_stats_replay.csv is rocprofv3 "
+                        f"serialised on one stream; profiles/{tag}_kernel_stats_replay.csv is rocprofv3 "
                         "--kernel-trace --stats of `bench.py --replay-only`",
         }
-        # HBM-side bytes per launch of that kernel from the committed PMC passes (collected with
-        # tools/collect_profiles.sh with --replay-only, i.e. these same launches; B=64 fp32 only -- the counters are per
-        # launch, so they do not depend on the step count)
-        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
-        if args.dtype == "f32" and B == 64 and os.path.exists(pmc_file):
-            pmc = json.load(open(pmc_file))
-            hit = pmc["kernels"].get(dom_name)
-            if hit:
-                roofline["traffic"] = hit["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/r1_pmc_traffic.json: " + pmc["source"]
+        # HBM-side bytes and MFMA-busy of that kernel from the committed PMC passes (tools/collect_profiles.sh
+        # with --replay-only, i.e. these same launches; the counters are per launch, so they do not depend on
+        # the step count).  Only for the two configurations the passes were collected on.
+        default_cfg = (args.dtype == "f32" and B == 64) or (args.dtype == "bf16" and B == 512)
+        pmc = load_profile_json(("pmc_traffic" if args.dtype == "f32" else "pmc_traffic_bf16_b512")) if default_cfg else None
+        if pmc and dom_name in pmc["kernels"]:
+            roofline["traffic"] = pmc["kernels"][dom_name]["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = pmc["source"]
+        busy = load_profile_json(("mfma_busy" if args.dtype == "f32" else "mfma_busy_bf16_b512")) if default_cfg else None
+        if busy and dom_name in busy["kernels"]:
+            roofline["mfma_busy"] = busy["kernels"][dom_name]["mfma_busy_of_kernel_time"]
+            roofline["mfma_busy_source"] = busy["source"]
         work = arch.work_per_frame()
         canon_bytes = work["canonical_bytes_f32"] // (1 if args.dtype == "f32" else 2)
         fps = world * B * args.steps / dt
         per_gpu = fps / world
         stage = arch.stagewise_bound(mfma_peak * 1e12, HBM_PEAK_GBS * 1e9, 4 if args.dtype == "f32" else 2)
+        two_lane = B >= 16 * lanes and lanes > 1
         result = {
             "metric": "160x160 lip-sync frames/sec (whole node)",
             "value": round(fps, 1),
@@ -245,8 +340,12 @@ def main():
                                    f"({'BASELINE configs[1]' if args.dtype == 'f32' else 'bf16 engine, BASELINE configs[2] family'}); "
                                    "frames sharded, weights broadcast once",
                        "global_batch": B * world, "parallelism": f"frames-dp{world}",
-                       "lanes_per_gpu": lanes if B >= 16 * lanes else 1,   # the engine runs small batches as one lane
-                       **({"rehearsal": f"{world} ranks share {n_dev} GPU(s), gloo"} if shared else {})},
+                       "lanes_per_gpu": lanes if two_lane else 1,   # the engine runs small batches as one lane
+                       "trunk_lanes": (trunk_lanes or lanes) if two_lane else 1,
+                       "world_size": dist.get_world_size() if world > 1 else 1,
+                       "backend": {"nccl": "nccl (RCCL)", "gloo": "gloo"}.get(backend, "none (single process)"),
+                       **({"rehearsal": f"{world} ranks share {n_dev} GPU(s), gloo"} if shared else {}),
+                       **({"strong_scaling": strong} if strong else {})},
             **({"replay_only": True} if args.replay_only else {}),
             "roofline": roofline,
             "whole_net": {"mfma_frac": round(per_gpu * work["flops"] / (mfma_peak * 1e12), 4),
@@ -257,6 +356,9 @@ def main():
                           "stagewise_bound_fps_per_gpu": round(stage["frames_per_s"], 1),
                           "frac_of_stagewise_bound": round(per_gpu / stage["frames_per_s"], 4)},
         }
+        if args.e2e and world == 1:
+            from calipsync_amd import frame_bench
+            result["config"]["e2e"] = frame_bench.run(net, dev, batch=B)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd_np, args.cpu_seconds)
     if world > 1:

@@ -31,6 +31,9 @@ _PROTOS = {
     "casync_packed_total": (c_i64, []),
     "casync_workspace_bytes": (c_i64, [C.c_int]),
     "casync_workspace_bytes_dt": (c_i64, [C.c_int, C.c_int]),
+    "casync_workspace_bytes_h": (c_i64, [C.c_void_p, C.c_int]),
+    "casync_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "casync_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
     "casync_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "casync_create_ex": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "casync_destroy": (None, [C.c_void_p]),
@@ -72,6 +75,7 @@ _PROTOS = {
 }
 
 EXPORTS = tuple(_PROTOS)
+ABI_VERSION = 2          # == CASYNC_ABI_VERSION of include/casync_hip.h this file was written against
 
 
 def lib_path() -> str:
@@ -92,13 +96,36 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"casync HIP engine not built: {path} is missing. Run `python -c 'import "
             "__graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
+    if _build.is_stale():
+        # a library older than its sources can carry an old struct stride / prototype: rebuild where a
+        # compiler exists (the build container, the GPU box), refuse it otherwise
+        try:
+            _build.build()
+        except Exception as exc:
+            raise RuntimeError(f"{path} is older than calipsync_amd/csrc and could not be rebuilt: {exc}") from exc
     lib = C.CDLL(path)
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)       # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    got = lib.casync_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"{path} has ABI version {got}, this binding needs {ABI_VERSION}: rebuild it "
+                           "(python -c 'import __graft_entry__ as g; g.build()')")
     _lib = lib
     return lib
+
+
+def set_option(name: str, value: int, handle=None) -> None:
+    """Set an engine switch by name (include/casync_hip.h, casync_set_option): on `handle`, or on the
+    process defaults (single-operator calls and engines created later) when handle is None."""
+    check(load().casync_set_option(handle, name.encode(), int(value)), f"casync_set_option({name})")
+
+
+def get_option(name: str, handle=None) -> int:
+    v = C.c_int()
+    check(load().casync_get_option(handle, name.encode(), C.byref(v)), f"casync_get_option({name})")
+    return v.value
 
 
 def check(status: int, what: str) -> int:

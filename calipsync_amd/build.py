@@ -5,13 +5,16 @@ from __future__ import annotations
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libcasync_hip.so")
-SOURCES = ["gemm.hip", "ops.hip", "ir_fused.hip", "attention.hip", "engine.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "ops.hip", "ir_fused.hip", "attention.hip", "engine.hip"]
 HEADERS = ["common.h", os.path.join("..", "..", "include", "casync_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
 def _hipcc() -> str:
@@ -21,26 +24,52 @@ def _hipcc() -> str:
     return exe
 
 
-def is_stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _header_paths():
+    return [os.path.join(CSRC, h) for h in HEADERS]
+
+
+def is_stale() -> bool:
+    """True when the library is missing or older than any of its sources / headers."""
+    return _newer(LIB_PATH, [os.path.join(CSRC, s) for s in SOURCES] + _header_paths())
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into calipsync_amd/lib/libcasync_hip.so."""
+    """Compile every HIP source for gfx950 (one object per source, in parallel) and link
+    calipsync_amd/lib/libcasync_hip.so."""
     if not force and not is_stale():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result", "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+
+    def compile_one(src: str):
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        path = os.path.join(CSRC, src)
+        if not force and not _newer(obj, [path] + _header_paths()):
+            return obj, None
+        cmd = [hipcc] + FLAGS + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        return obj, (res.stdout + res.stderr if res.returncode else None)
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:
+        results = list(pool.map(compile_one, SOURCES))
+    errors = [err for _, err in results if err]
+    if errors:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(errors))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + [obj for obj, _ in results]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     return LIB_PATH
 
 

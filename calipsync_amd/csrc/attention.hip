@@ -175,16 +175,13 @@ int launch_cross_attention(const void* q, int ldq, const void* k, int ldk, const
                      ld_res >= CV && ld_out >= CV,
                  "cross_attention: bad leading dimensions");
   CASYNC_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0, "cross_attention: Q/K alignment");
-  static bool attr_set = false;
-  if (!attr_set) {
-    CASYNC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cross_attention_kernel<float>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES));
-    CASYNC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cross_attention_kernel<bf16_t>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES));
-    attr_set = true;
-  }
+  static unsigned long long once_f32 = 0, once_bf16 = 0;
+  if (int st = dtype == DT_BF16
+                   ? casync_ensure_dyn_lds(&once_bf16, reinterpret_cast<const void*>(cross_attention_kernel<bf16_t>), ATT_LDS_BYTES)
+                   : casync_ensure_dyn_lds(&once_f32, reinterpret_cast<const void*>(cross_attention_kernel<float>), ATT_LDS_BYTES))
+    return st;
   // frame x 32-query block x channel split: enough workgroups to fill 256 CUs x ~4, no more
-  static const int forced_nz = [] { const char* e = getenv("CASYNC_ATT_NZ"); return e && *e ? atoi(e) : 0; }();
+  const int forced_nz = casync_opts().att_nz;
   int nz = batch <= 24 ? 4 : (batch <= 160 ? 2 : 1);   // measured: 4 wins up to 24 frames, 2 from 32 (a lane of B=64)
   if (forced_nz == 1 || forced_nz == 2 || forced_nz == 4) nz = forced_nz;
   const dim3 grid(batch, 4, nz);

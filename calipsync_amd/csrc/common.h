@@ -38,6 +38,43 @@ __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : v * CASYN
 // thread-local error text behind casync_last_error()
 void casync_set_error(const char* fmt, ...);
 
+// ---- tuning options ---------------------------------------------------------------------------
+// Every switch of the engine.  The process defaults are read from the CASYNC_* environment ONCE (first
+// use); casync_create copies them into the handle; casync_set_option changes a handle's copy (or, with
+// a null handle, the process defaults that the single-operator API and later handles see).  Nothing on
+// a launch path calls getenv.
+struct CasyncOptions {
+  int lanes = 2;             // CASYNC_LANES: concurrent sub-batch lanes (1..4) from 2*16 frames up
+  int trunk_lanes = 0;       // CASYNC_TRUNK_LANES: lanes of the 10x10 trunk (0 = same as `lanes`; 1 = the
+                             //   lanes join before the fusion MLP and the trunk runs as one stream-K lane)
+  int overlap = 1;           // CASYNC_OVERLAP: audio encoder on its own stream per lane
+  int gemm_streamk = 1;      // CASYNC_GEMM_STREAMK: stream-K remainders in single-lane runs
+  int gemm_glds = 2;         // CASYNC_GEMM_GLDS: LDS-DMA ring GEMM: 0 off, 1 bf16 only, 2 both types
+  int gemm_cfg = -1;         // CASYNC_GEMM_CFG: force one tile configuration
+  int gemm_persist = 1;      // CASYNC_GEMM_PERSIST: persistent grid of the register-staged GEMM
+  int gemm_conc = 3;         // CASYNC_GEMM_CONC: tile policy when lanes share the chip
+  int gemm_conc_tiles = 2048;  // CASYNC_GEMM_CONC_TILES
+  int fuse_ir = 1;           // CASYNC_FUSE_IR: fused inverted-residual kernel
+  int fuse_up = 1;           // CASYNC_FUSE_UP: bilinear upsample folded into up3/up4
+  int fuse_min_hw = 32;      // CASYNC_FUSE_MIN_HW: lowest resolution the fused kernel is used at
+  int fuse_q = 1;            // CASYNC_FUSE_Q: query projection as 64 extra columns of the p_1 GEMM
+  int dw_lds = 1;            // CASYNC_DW_LDS: LDS-slab depthwise kernel
+  int dw_lds_bytes = 32768;  // CASYNC_DW_LDS_BYTES
+  int conv_im2col = 0;       // CASYNC_CONV_IM2COL: dense 3x3 via im2col + GEMM instead of the implicit GEMM
+  int att_nz = 0;            // CASYNC_ATT_NZ: channel split of the attention kernel (0 = by batch)
+};
+CasyncOptions& casync_default_options();      // process defaults (environment read once, thread-safe)
+const CasyncOptions& casync_opts();           // options of the call in progress on this thread
+int casync_option_ref(CasyncOptions& o, const char* name, int** slot);   // name -> field (CASYNC_ERR_ARG if unknown)
+struct CasyncOptScope {                       // makes `o` the current options of this thread for its lifetime
+  const CasyncOptions* prev;
+  explicit CasyncOptScope(const CasyncOptions* o);
+  ~CasyncOptScope();
+};
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device): `once_mask` is a per-kernel-instance
+// bit mask of devices already done (atomic; setting the attribute twice is harmless)
+int casync_ensure_dyn_lds(unsigned long long* once_mask, const void* fn, int bytes);
+
 #define CASYNC_CHECK_HIP(expr)                                                        \
   do {                                                                                \
     hipError_t e__ = (expr);                                                          \
@@ -128,7 +165,7 @@ int launch_conv3x3_gemm(const void* in, const void* w, void* out, int ldc, int b
                         int cout, int stride, int pad, const GemmEpilogue& epi, hipStream_t stream,
                         int dtype = DT_F32);
 const char* conv3x3_gemm_kernel_name(int batch, int h, int wdt, int cin, int cout, int stride, int pad,
-                                     int dtype = DT_F32, bool concurrent = false);
+                                     int dtype = DT_F32, bool concurrent = false, bool stream_k = false);
 
 // ---- other operators -------------------------------------------------------
 int launch_dw3x3(const void* in, const float* w, const float* bias, void* out, int batch, int h,

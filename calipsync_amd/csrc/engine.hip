@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -113,6 +115,10 @@ const Layout& layout() {
       l.add(p + ".p1.b", 512);
       l.add(p + ".q.w", 64ll * 512);
       l.add(p + ".q.b", 64);
+      // rows 0..511 = p_1, rows 512..575 = query_conv o p_1 composed on the host in float64
+      // (module/unet.py:201,209,256,264): q comes out of the p_1 GEMM as 64 extra columns
+      l.add(p + ".p1q.w", 576ll * 1024);
+      l.add(p + ".p1q.b", 576);
       l.add(p + ".gamma", 1);
       l.add(p + ".b1.w", 1024ll * 512);  // block bn folded in
       l.add(p + ".b1.b", 1024);
@@ -141,6 +147,30 @@ struct Ptr {
   operator const void*() const { return p; }
 };
 
+// Largest expanded (2x) tensor an UN-fused inverted residual of the plan writes, per frame: the E1/E2
+// slots are sized for it.  With the fused kernels on (default) that is up2.0's 40x40x512, not the
+// 160x160x128 of up4.0 the fused kernel keeps in LDS (19.6 MB per frame less workspace).
+bool ir_is_fused(const CasyncOptions& o, const IR& b) {
+  return o.fuse_ir && b.hw_in >= o.fuse_min_hw && ir_fused_supported(b.cin, b.cout, b.stride);
+}
+bool up_is_fused(const CasyncOptions& o, const IR& b0) {
+  return o.fuse_ir && o.fuse_up && b0.hw_in >= o.fuse_min_hw && ir_fused_up_supported(b0.cin, b0.cout);
+}
+int64_t max_unfused_expand(const CasyncOptions& o) {
+  int64_t mx = 0;
+  auto see = [&](const IR& b, bool fused) {
+    if (!fused) mx = std::max<int64_t>(mx, (int64_t)b.hw_in * b.hw_in * b.cexp());
+  };
+  for (auto& st : kDown)
+    for (auto& b : st) see(b, ir_is_fused(o, b));
+  for (auto& b : kFuse) see(b, ir_is_fused(o, b));
+  for (auto& st : kUp) {
+    see(st[0], up_is_fused(o, st[0]) || ir_is_fused(o, st[0]));
+    see(st[1], ir_is_fused(o, st[1]));
+  }
+  return mx;
+}
+
 struct Arena {
   // per-frame float counts; pointers are filled by bind()
   struct Buf {
@@ -152,7 +182,7 @@ struct Arena {
   enum Id {
     CAT4, CAT3, CAT2, CAT1, CATA, E1, E2, T0, U4, F, FM, U1, U2, U3,
     A0, AC1, AC2, IM, AC3, AC4, AC5, AC6, AE1, AE2,
-    H, TX, OX0, OX1, OX2, OX3, KX, KXF, P1, AO, Q, KV, COUNT
+    H, TX, OX0, OX1, OX2, OX3, KX, KXF, P1Q, AO, Q, KV, COUNT
   };
   Buf b[COUNT] = {
       {"cat4", 160 * 160 * 64, 0},  {"cat3", 80 * 80 * 128, 0},  {"cat2", 40 * 40 * 256, 0},
@@ -165,10 +195,14 @@ struct Arena {
       {"AC6", 100 * 512, 0},        {"AE1", 131072, 0},          {"AE2", 131072, 0},
       {"H", 100 * 1024, 0},         {"TX", 100 * 1024, 0},       {"OX0", 100 * 1024, 0},
       {"OX1", 100 * 1024, 0},       {"OX2", 100 * 1024, 0},      {"OX3", 100 * 1024, 0},
-      {"KX", 100 * 1024, 0},        {"KXF", 100 * 1024, 0},      {"P1", 100 * 512, 0},
+      {"KX", 100 * 1024, 0},        {"KXF", 100 * 1024, 0},      {"P1Q", 100 * 576, 0},
       {"AO", 100 * 512, 0},         {"Q", 100 * 64, 0},          {"KV", 100 * kBlocks * kKV, 0}};
-  static int64_t bytes(int batch, int esz = 4) {
-    Arena a;
+  explicit Arena(const CasyncOptions& o) {
+    b[E1].per_frame = b[E2].per_frame = max_unfused_expand(o);
+    if (!o.conv_im2col) b[IM].per_frame = 0;   // the implicit-GEMM convs need no patch buffer
+  }
+  static int64_t bytes(const CasyncOptions& o, int batch, int esz = 4) {
+    Arena a(o);
     int64_t tot = 0;
     for (auto& x : a.b) tot += (x.per_frame * batch + 63) / 64 * 64;
     return tot * (int64_t)esz;
@@ -186,6 +220,20 @@ struct Arena {
     for (auto& x : b) x.p += x.per_frame * (int64_t)b0 * esz;
   }
   Ptr operator[](Id i) const { return Ptr{b[i].p, esz}; }
+};
+
+// hipSetDevice for the life of a scope (the caller's device is restored on exit)
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) err = hipSetDevice(dev);
+    else if (err == hipSuccess) prev = -1;   // nothing to restore
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
 };
 
 }  // namespace
@@ -209,9 +257,10 @@ struct casync_engine {
   static constexpr int kMaxLanes = 4;
   hipStream_t lane_s[kMaxLanes] = {};   // [0] unused (caller's stream)
   hipStream_t aux[kMaxLanes] = {};
-  hipEvent_t ev_fork[kMaxLanes] = {}, ev_join[kMaxLanes] = {}, ev_done[kMaxLanes] = {};
-  hipEvent_t ev_start = nullptr;
+  hipEvent_t ev_fork[kMaxLanes] = {}, ev_join[kMaxLanes] = {}, ev_done[kMaxLanes] = {}, ev_mid[kMaxLanes] = {};
+  hipEvent_t ev_start = nullptr, ev_start2 = nullptr;
   bool streams_ready = false;
+  CasyncOptions opt;         // this handle's switches: process defaults at create, casync_set_option afterwards
   const float* W(const std::string& name) const { return w + layout().off(name); }
   // GEMM weight matrix in the engine's storage type
   const void* WG(const std::string& name) const {
@@ -269,11 +318,6 @@ struct Runner {
   }
 };
 
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
-
 struct Plan {
   const casync_engine& e;
   Arena ar;
@@ -293,9 +337,7 @@ struct Plan {
   const float* win_feat = nullptr;
   int win_steps = 0;
   const int* win_idx = nullptr;
-  bool fuse_ir = env_int("CASYNC_FUSE_IR", 1) != 0;      // A/B switch for the fused IR kernel
-  bool fuse_up = env_int("CASYNC_FUSE_UP", 1) != 0;      // fold the bilinear upsample into up3/up4
-  int fuse_min_hw = env_int("CASYNC_FUSE_MIN_HW", 32);   // fuse stages at least this large
+  const CasyncOptions& o = e.opt;
 
   // GEMM wrapper with work accounting (algorithmic bytes: A + C once, W once)
   int dt() const { return e.dtype; }
@@ -305,7 +347,8 @@ struct Plan {
   }
 
   void gemm(const std::string& tag, const void* a, int lda, const std::string& wname, void* c,
-            int ldc, long long m, int n, int k, GemmEpilogue epi, const std::string& bname = "") {
+            int ldc, long long m, int n, int k, GemmEpilogue epi, const std::string& bname = "",
+            double alg_flops = 0) {
     const void* w = e.WG(wname);
     epi.bias = e.W(bname.empty() ? wname.substr(0, wname.size() - 1) + "b" : bname);
     const double es = dtype_size(dt());
@@ -318,7 +361,8 @@ struct Plan {
       epi.sk_cnt = reinterpret_cast<unsigned*>(ctx + kStreamKFloats * 4);
     }
     epi.concurrent = concurrent ? 1 : 0;
-    r.run(tag.c_str(), pw_gemm_kernel_name((int)m, n, k, epi.sk_ws != nullptr, dt(), concurrent), 2.0 * m * n * k, bytes,
+    r.run(tag.c_str(), pw_gemm_kernel_name((int)m, n, k, epi.sk_ws != nullptr, dt(), concurrent),
+          alg_flops > 0 ? alg_flops : 2.0 * m * n * k, bytes,
           [&] { return launch_pw_gemm(a, lda, w, c, ldc, (int)m, n, k, epi, r.s, dt()); });
   }
 
@@ -330,7 +374,7 @@ struct Plan {
     const long long m = (long long)B * ho * ho;
     GemmEpilogue ep;
     ep.act = 1;
-    if (env_int("CASYNC_CONV_IM2COL", 0)) {
+    if (o.conv_im2col) {
       r.run((tag + ".im2col").c_str(), kname("im2col3x3_kernel").c_str(), 0,
             dtype_size(dt()) * (double)B * ((double)hw * hw * cin + (double)ho * ho * 9 * cin),
             [&] { return launch_im2col3x3(in, ar[Arena::IM], B, hw, hw, cin, stride, pad, r.s, dt()); });
@@ -344,7 +388,7 @@ struct Plan {
       ep.sk_cnt = reinterpret_cast<unsigned*>(ctx + kStreamKFloats * 4);
     }
     const double es = dtype_size(dt());
-    r.run(tag.c_str(), conv3x3_gemm_kernel_name(B, hw, hw, cin, cout, stride, pad, dt(), concurrent),
+    r.run(tag.c_str(), conv3x3_gemm_kernel_name(B, hw, hw, cin, cout, stride, pad, dt(), concurrent, ep.sk_ws != nullptr),
           2.0 * m * cout * 9 * cin, es * ((double)B * hw * hw * cin + (double)m * cout + 9.0 * cin * cout), [&] {
       return launch_conv3x3_gemm(in, e.WG(wname), out, cout, B, hw, hw, cin, cout, stride, pad, ep, r.s, dt());
     });
@@ -355,7 +399,7 @@ struct Plan {
           const GemmEpilogue* extra = nullptr) {
     const std::string p = b.prefix;
     const long long m_in = (long long)B * b.hw_in * b.hw_in, m_out = (long long)B * b.hw_out() * b.hw_out();
-    if (fuse_ir && !extra && b.hw_in >= fuse_min_hw && ir_fused_supported(b.cin, b.cout, b.stride)) {
+    if (!extra && ir_is_fused(o, b)) {
       const double flops = 2.0 * (m_in * (double)b.cin * b.cexp() + 9.0 * m_out * b.cexp() +
                                   (double)m_out * b.cexp() * b.cout);
       r.run((p + ".fused").c_str(), ir_fused_kernel_name(b.cin, b.cout, b.stride, dt()), flops,
@@ -384,7 +428,8 @@ struct Plan {
     gemm(p + ".pw2", e2, b.cexp(), p + ".pw2.w", out, ld_out, m_out, b.cout, b.cexp(), ep2);
   }
 
-  void forward(const float* x, const float* audio, float* out) {
+  // Phase 1 of Model.forward: audio encoder || face encoder down to x5 (module/unet.py:315-321).
+  void encode(const float* x, const float* audio) {
     using A = Arena;
     Ptr E1 = ar[A::E1], E2 = ar[A::E2], T0 = ar[A::T0];
     // The audio encoder and the face encoder are independent until the fusion MLP; with a
@@ -440,6 +485,13 @@ struct Plan {
       casync_set_error("forward: join of the audio stream failed");
       r.status = CASYNC_ERR_HIP;
     }
+  }
+
+  // Phase 2: the 10x10 trunk -- fusion MLP, four attention blocks, fuse_conv (module/unet.py:323-337).
+  // All of it is [B*100, C] GEMMs (+ the attention core and four small depthwise convs).
+  void trunk() {
+    using A = Arena;
+    Ptr E1 = ar[A::E1], E2 = ar[A::E2], T0 = ar[A::T0];
     // ---------------- fusion (module/unet.py:323-326): tx = bn_tx(cat + mlp(cat))
     const long long M10 = (long long)B * 100;
     Ptr CATA = ar[A::CATA];
@@ -460,13 +512,25 @@ struct Plan {
     Ptr prev = ar[A::TX];
     for (int i = 0; i < kBlocks; ++i) {
       const std::string p = "attention_blocks." + std::to_string(i);
-      gemm(p + ".p1", prev, 1024, p + ".p1.w", ar[A::P1], 512, M10, 512, 1024, GemmEpilogue());
-      gemm(p + ".q", ar[A::P1], 512, p + ".q.w", ar[A::Q], 64, M10, 64, 512, GemmEpilogue());
+      // ox = p_1(x) lands in columns 0..511 of P1Q (ld 576); q = query_conv(ox) in columns 512..575:
+      // either as 64 extra output columns of the same GEMM (weights composed on the host, default) or
+      // by the reference's own second GEMM on ox
+      Ptr P1 = ar[A::P1Q], Qp = ar[A::P1Q] + 512;
+      int ldq = 576;
+      if (o.fuse_q) {
+        gemm(p + ".p1q", prev, 1024, p + ".p1q.w", P1, 576, M10, 576, 1024, GemmEpilogue(), "",
+             2.0 * M10 * (1024.0 * 512 + 512.0 * 64));
+      } else {
+        gemm(p + ".p1", prev, 1024, p + ".p1.w", P1, 576, M10, 512, 1024, GemmEpilogue());
+        gemm(p + ".q", P1, 576, p + ".q.w", ar[A::Q], 64, M10, 64, 512, GemmEpilogue());
+        Qp = ar[A::Q];
+        ldq = 64;
+      }
       Ptr kv = ar[A::KV] + i * kKV;
       r.run((p + ".attn").c_str(), kname("cross_attention_kernel").c_str(), 2.0 * M10 * 100 * (64 + 512),
             dtype_size(dt()) * (double)M10 * (64 + kKV + 1024), [&] {
-        return launch_cross_attention(ar[A::Q], 64, kv, kBlocks * kKV, kv + 64, kBlocks * kKV, ar[A::P1],
-                                      512, e.W(p + ".gamma"), ar[A::AO], 512, B, r.s, dt());
+        return launch_cross_attention(Qp, ldq, kv, kBlocks * kKV, kv + 64, kBlocks * kKV, P1, 576,
+                                      e.W(p + ".gamma"), ar[A::AO], 512, B, r.s, dt());
       });
       GemmEpilogue ep;  // lrelu(bn(b_1(ox) + tx)); kx += ox; last block also lrelu(bn_kx(kx))
       ep.pre_res = ar[A::TX];
@@ -489,6 +553,12 @@ struct Plan {
     ir(kFuse[1], T0, 512, ar[A::FM], 512, E1, E2);
     ir(kFuse[2], ar[A::FM], 512, T0, 256, E1, E2);
     ir(kFuse[3], T0, 256, ar[A::F], 256, E1, E2);
+  }
+
+  // Phase 3: decoder + head (module/unet.py:338-344).
+  void decode(float* out) {
+    using A = Arena;
+    Ptr E1 = ar[A::E1], E2 = ar[A::E2], T0 = ar[A::T0];
     // ---------------- decoder (module/unet.py:338-341)
     Ptr lo = ar[A::F];
     Ptr cat[4] = {ar[A::CAT1], ar[A::CAT2], ar[A::CAT3], ar[A::CAT4]};
@@ -497,7 +567,7 @@ struct Plan {
     for (int i = 0; i < 4; ++i) {
       const int cc = 2 * c;  // concat width
       const IR& b0 = kUp[i][0];
-      if (fuse_ir && fuse_up && 2 * hw >= fuse_min_hw && ir_fused_up_supported(b0.cin, b0.cout)) {
+      if (up_is_fused(o, b0)) {
         // bilinear x2 folded into the fused block's input load: up(x) is never materialised
         const std::string p = b0.prefix;
         const double m = (double)B * 4 * hw * hw;
@@ -537,9 +607,9 @@ int check_forward_args(casync_handle h, const float* x, const float* a, float* o
     casync_set_error("forward: weights not loaded");
     return CASYNC_ERR_STATE;
   }
-  if (ws_bytes < Arena::bytes(batch, dtype_size(h->dtype))) {
+  if (ws_bytes < Arena::bytes(h->opt, batch, dtype_size(h->dtype))) {
     casync_set_error("forward: workspace %lld B < required %lld B", (long long)ws_bytes,
-                     (long long)Arena::bytes(batch, dtype_size(h->dtype)));
+                     (long long)Arena::bytes(h->opt, batch, dtype_size(h->dtype)));
     return CASYNC_ERR_STATE;
   }
   CASYNC_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
@@ -553,7 +623,7 @@ int check_forward_args(casync_handle h, const float* x, const float* a, float* o
 // ====================================================================== C ABI
 extern "C" {
 
-int casync_abi_version(void) { return 1; }
+int casync_abi_version(void) { return CASYNC_ABI_VERSION; }
 int casync_packed_count(void) { return (int)layout().items.size(); }
 const char* casync_packed_name(int i) {
   return (i >= 0 && i < casync_packed_count()) ? layout().items[i].name.c_str() : nullptr;
@@ -561,9 +631,29 @@ const char* casync_packed_name(int i) {
 int64_t casync_packed_offset(int i) { return (i >= 0 && i < casync_packed_count()) ? layout().items[i].offset : -1; }
 int64_t casync_packed_size(int i) { return (i >= 0 && i < casync_packed_count()) ? layout().items[i].size : -1; }
 int64_t casync_packed_total(void) { return layout().total; }
-int64_t casync_workspace_bytes(int batch) { return batch > 0 ? Arena::bytes(batch, 4) : -1; }
+int64_t casync_workspace_bytes(int batch) {
+  return batch > 0 ? Arena::bytes(casync_default_options(), batch, 4) : -1;
+}
 int64_t casync_workspace_bytes_dt(int batch, int dtype) {
-  return batch > 0 && (dtype == DT_F32 || dtype == DT_BF16) ? Arena::bytes(batch, dtype_size(dtype)) : -1;
+  return batch > 0 && (dtype == DT_F32 || dtype == DT_BF16)
+             ? Arena::bytes(casync_default_options(), batch, dtype_size(dtype)) : -1;
+}
+int64_t casync_workspace_bytes_h(casync_handle h, int batch) {
+  return h && batch > 0 ? Arena::bytes(h->opt, batch, dtype_size(h->dtype)) : -1;
+}
+
+int casync_set_option(casync_handle h, const char* name, int value) {
+  int* slot = nullptr;
+  const int st = casync_option_ref(h ? h->opt : casync_default_options(), name, &slot);
+  if (st == CASYNC_OK) *slot = value;
+  return st;
+}
+int casync_get_option(casync_handle h, const char* name, int* value) {
+  CASYNC_REQUIRE(value, "get_option: null out");
+  int* slot = nullptr;
+  const int st = casync_option_ref(h ? h->opt : casync_default_options(), name, &slot);
+  if (st == CASYNC_OK) *value = *slot;
+  return st;
 }
 
 int casync_create(int device_id, casync_handle* out) { return casync_create_ex(device_id, DT_F32, out); }
@@ -586,15 +676,14 @@ int casync_create_ex(int device_id, int dtype, casync_handle* out) {
   casync_engine* e = new casync_engine();
   e->device = device_id;
   e->dtype = dtype;
+  e->opt = casync_default_options();   // the environment was read once; this handle keeps its own copy
   {
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceGuard guard(device_id);
     const size_t bytes = (size_t)casync_engine::kMaxLanes * 2 * kStreamKBytes;
-    hipError_t err = hipSetDevice(device_id);
+    hipError_t err = guard.err;
     if (err == hipSuccess) err = hipMalloc((void**)&e->sk, bytes);
     if (err == hipSuccess) err = hipMemset(e->sk, 0, bytes);
     if (err == hipSuccess) err = hipDeviceSynchronize();
-    (void)hipSetDevice(prev);
     if (err != hipSuccess) {
       casync_set_error("create: stream-K scratch (%zu bytes): %s", bytes, hipGetErrorString(err));
       if (e->sk) (void)hipFree(e->sk);
@@ -608,6 +697,7 @@ int casync_create_ex(int device_id, int dtype, casync_handle* out) {
 
 void casync_destroy(casync_handle h) {
   if (!h) return;
+  DeviceGuard guard(h->device);
   if (h->streams_ready) {
     for (int l = 0; l < casync_engine::kMaxLanes; ++l) {
       if (h->lane_s[l]) { (void)hipStreamSynchronize(h->lane_s[l]); (void)hipStreamDestroy(h->lane_s[l]); }
@@ -615,20 +705,22 @@ void casync_destroy(casync_handle h) {
       if (h->ev_fork[l]) (void)hipEventDestroy(h->ev_fork[l]);
       if (h->ev_join[l]) (void)hipEventDestroy(h->ev_join[l]);
       if (h->ev_done[l]) (void)hipEventDestroy(h->ev_done[l]);
+      if (h->ev_mid[l]) (void)hipEventDestroy(h->ev_mid[l]);
     }
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    if (h->ev_start2) (void)hipEventDestroy(h->ev_start2);
   }
-  if (h->owned) {
-    (void)hipSetDevice(h->device);
-    (void)hipFree(h->owned);
-  }
+  if (h->owned) (void)hipFree(h->owned);
   if (h->w16) (void)hipFree(h->w16);
   if (h->sk) (void)hipFree(h->sk);
   delete h;
 }
 
+// bf16 image of the packed buffer; runs on the engine's device whatever the caller's current device is
 static int refresh_bf16_weights(casync_handle h, int64_t n) {
   if (h->dtype != DT_BF16) return CASYNC_OK;
+  DeviceGuard guard(h->device);
+  CASYNC_CHECK_HIP(guard.err);
   if (!h->w16) CASYNC_CHECK_HIP(hipMalloc((void**)&h->w16, n * sizeof(bf16_t)));
   const long long blocks = (n / 4 + 255) / 256;   // packed total is a multiple of 64 floats
   hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, h->w, h->w16, (long long)n);
@@ -641,9 +733,12 @@ int casync_load_weights_host(casync_handle h, const float* packed, int64_t n_flo
   CASYNC_REQUIRE(h && packed, "load_weights: null");
   CASYNC_REQUIRE(n_floats == layout().total, "load_weights: %lld floats, layout needs %lld",
                  (long long)n_floats, (long long)layout().total);
-  CASYNC_CHECK_HIP(hipSetDevice(h->device));
-  if (!h->owned) CASYNC_CHECK_HIP(hipMalloc((void**)&h->owned, n_floats * sizeof(float)));
-  CASYNC_CHECK_HIP(hipMemcpy(h->owned, packed, n_floats * sizeof(float), hipMemcpyHostToDevice));
+  {
+    DeviceGuard guard(h->device);
+    CASYNC_CHECK_HIP(guard.err);
+    if (!h->owned) CASYNC_CHECK_HIP(hipMalloc((void**)&h->owned, n_floats * sizeof(float)));
+    CASYNC_CHECK_HIP(hipMemcpy(h->owned, packed, n_floats * sizeof(float), hipMemcpyHostToDevice));
+  }
   h->w = h->owned;
   return refresh_bf16_weights(h, n_floats);
 }
@@ -653,37 +748,166 @@ int casync_load_weights_device(casync_handle h, const float* packed_dev, int64_t
   CASYNC_REQUIRE(n_floats == layout().total, "load_weights_device: %lld floats, layout needs %lld",
                  (long long)n_floats, (long long)layout().total);
   CASYNC_REQUIRE(((uintptr_t)packed_dev % 256) == 0, "load_weights_device: buffer must be 256-B aligned");
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, packed_dev) == hipSuccess && attr.type == hipMemoryTypeDevice)
+    CASYNC_REQUIRE(attr.device == h->device, "load_weights_device: buffer lives on device %d, the engine on %d",
+                   attr.device, h->device);
+  else
+    (void)hipGetLastError();
   h->w = packed_dev;
   return refresh_bf16_weights(h, n_floats);
 }
 
-static int ensure_streams(casync_handle h) {
+static int ensure_streams(casync_handle h) {   // caller holds a DeviceGuard for h->device
   if (h->streams_ready) return CASYNC_OK;
-  // created lazily on the caller's current device (== h->device)
   CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
+  CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_start2, hipEventDisableTiming));
   for (int l = 0; l < casync_engine::kMaxLanes; ++l) {
     if (l) CASYNC_CHECK_HIP(hipStreamCreateWithFlags(&h->lane_s[l], hipStreamNonBlocking));
     CASYNC_CHECK_HIP(hipStreamCreateWithFlags(&h->aux[l], hipStreamNonBlocking));
     CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork[l], hipEventDisableTiming));
     CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming));
     CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_done[l], hipEventDisableTiming));
+    CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_mid[l], hipEventDisableTiming));
   }
   h->streams_ready = true;
   return CASYNC_OK;
 }
 
-// One lane + stream-K GEMMs below 32 frames, two plain-tile lanes from there on (measured with
-// tools/latency_sweep.py, one lane vs two: B=8 +19 %, B=24 +4 %, B=32 -3.5 %, B=64 +-0.5 %,
-// B=96 -3.4 %, B=256 -0.4 %; bf16 B=64..512 -1.5..-3 %).
+// Lanes: from 2 x 16 frames up the batch is cut into `lanes` contiguous sub-batches that run
+// concurrently (lane 0 on the caller's stream), so one lane's memory-bound kernels and kernel tails
+// overlap another lane's MFMA-bound GEMMs; below that one lane with stream-K GEMM remainders
+// (tools/latency_sweep.py, one lane vs two: B=8 +19 %, B=24 +4 %, B=32 -3.5 %, B=96 -3.4 %).
+// trunk_lanes = 1 ("hybrid"): the lanes join before the fusion MLP, the 10x10 trunk (all GEMMs with
+// M = B*100 rows) runs once over the whole batch with stream-K remainders, and the lanes fork again
+// for the decoder.
 constexpr int kMinLaneBatch = 16;
 
-static int forward_impl(casync_handle h, const float* x, const float* a, const float* feat, int n_steps,
-                        const int* idx, float* out, int batch, void* ws, int64_t ws_bytes,
-                        casync_stream stream);
+struct FwdArgs {
+  const float* x;
+  const float* a;        // NCHW windows (null when `feat` is set)
+  const float* feat;     // whole HuBERT array + per-frame indices, gathered on the device
+  int n_steps;
+  const int* idx;
+  float* out;
+  int batch;
+  void* ws;
+};
+
+// The launch sequence of one forward.  prof == null: enqueue on the caller's stream + engine streams,
+// no host sync.  prof != null: the SAME launches (same lanes, sub-batches, kernels, grids) serialised
+// on the caller's stream with an event pair around each; synchronises.
+static int run_forward(casync_handle h, const FwdArgs& A, hipStream_t caller, std::vector<casync_kernel_time>* prof) {
+  const CasyncOptions& o = h->opt;
+  CasyncOptScope scope(&h->opt);
+  DeviceGuard guard(h->device);
+  CASYNC_CHECK_HIP(guard.err);
+  const bool serial = prof != nullptr;
+  const bool overlap = o.overlap != 0 && !serial;
+  int lanes = o.lanes < 1 ? 1 : (o.lanes > casync_engine::kMaxLanes ? casync_engine::kMaxLanes : o.lanes);
+  if (A.batch < kMinLaneBatch * lanes) lanes = 1;  // small batches are latency-bound: cutting them only adds launches
+  const bool hybrid = lanes > 1 && o.trunk_lanes == 1;
+  if (overlap || lanes > 1) {
+    const int st = ensure_streams(h);
+    if (st != CASYNC_OK) return st;
+  }
+  const int esz = dtype_size(h->dtype);
+  bool forked = false;
+  // On an error after work went to the engine's own streams, drain them before returning: the caller
+  // will drop the workspace, and torch's allocator only knows about the caller's stream.
+  auto fail = [&](int st) {
+    if (forked)
+      for (int l = 0; l < casync_engine::kMaxLanes; ++l) {
+        if (h->lane_s[l]) (void)hipStreamSynchronize(h->lane_s[l]);
+        if (h->aux[l]) (void)hipStreamSynchronize(h->aux[l]);
+      }
+    return st;
+  };
+#define FWD_HIP(expr)                                                                           \
+  do {                                                                                          \
+    hipError_t e__ = (expr);                                                                    \
+    if (e__ != hipSuccess) {                                                                    \
+      casync_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__));   \
+      return fail(CASYNC_ERR_HIP);                                                              \
+    }                                                                                           \
+  } while (0)
+
+  int b0s[casync_engine::kMaxLanes], bls[casync_engine::kMaxLanes];
+  for (int l = 0, b0 = 0; l < lanes; ++l) {
+    bls[l] = A.batch / lanes + (l < A.batch % lanes ? 1 : 0);
+    b0s[l] = b0;
+    b0 += bls[l];
+  }
+  auto lane_stream = [&](int l) { return serial || l == 0 ? caller : h->lane_s[l]; };
+  // one phase of one lane (or of the whole batch: l = 0, b0 = 0, bl = batch)
+  auto run_phase = [&](int phase, int l, int b0, int bl, bool stream_k, bool concurrent) -> int {
+    Runner r;
+    r.s = lane_stream(l);
+    r.profile = serial;
+    Plan p{*h, Arena(o), r, bl};
+    p.lane = l;
+    p.stream_k = stream_k;
+    p.concurrent = concurrent;
+    p.ar.bind(A.ws, A.batch, esz);
+    p.ar.slice(b0);
+    if (overlap) {
+      p.aux = h->aux[l];
+      p.ev_fork = h->ev_fork[l];
+      p.ev_join = h->ev_join[l];
+      forked = true;
+    }
+    if (A.feat) {
+      p.win_feat = A.feat;
+      p.win_steps = A.n_steps;
+      p.win_idx = A.idx + b0;
+    }
+    if (phase == 0) p.encode(A.x + (size_t)b0 * 6 * 160 * 160, A.feat ? nullptr : A.a + (size_t)b0 * 32 * 32 * 32);
+    else if (phase == 1) p.trunk();
+    else p.decode(A.out + (size_t)b0 * 3 * 160 * 160);
+    r.finish();
+    if (prof) prof->insert(prof->end(), r.rec.begin(), r.rec.end());
+    return r.status;
+  };
+
+  if (lanes > 1 && !serial) {
+    FWD_HIP(hipEventRecord(h->ev_start, caller));
+    for (int l = 1; l < lanes; ++l) FWD_HIP(hipStreamWaitEvent(h->lane_s[l], h->ev_start, 0));
+    forked = true;
+  }
+  const bool conc = lanes > 1;
+  for (int l = 0; l < lanes; ++l)
+    if (int st = run_phase(0, l, b0s[l], bls[l], !conc, conc)) return fail(st);
+  if (hybrid) {
+    if (!serial)
+      for (int l = 1; l < lanes; ++l) {
+        FWD_HIP(hipEventRecord(h->ev_mid[l], h->lane_s[l]));
+        FWD_HIP(hipStreamWaitEvent(caller, h->ev_mid[l], 0));
+      }
+    if (int st = run_phase(1, 0, 0, A.batch, true, false)) return fail(st);
+    if (!serial) {
+      FWD_HIP(hipEventRecord(h->ev_start2, caller));
+      for (int l = 1; l < lanes; ++l) FWD_HIP(hipStreamWaitEvent(h->lane_s[l], h->ev_start2, 0));
+    }
+  } else {
+    for (int l = 0; l < lanes; ++l)
+      if (int st = run_phase(1, l, b0s[l], bls[l], !conc, conc)) return fail(st);
+  }
+  for (int l = 0; l < lanes; ++l)
+    if (int st = run_phase(2, l, b0s[l], bls[l], !conc, conc)) return fail(st);
+  if (lanes > 1 && !serial)
+    for (int l = 1; l < lanes; ++l) {
+      FWD_HIP(hipEventRecord(h->ev_done[l], h->lane_s[l]));
+      FWD_HIP(hipStreamWaitEvent(caller, h->ev_done[l], 0));
+    }
+#undef FWD_HIP
+  return CASYNC_OK;
+}
 
 int casync_forward(casync_handle h, const float* x, const float* a, float* out, int batch, void* ws,
                    int64_t ws_bytes, casync_stream stream) {
-  return forward_impl(h, x, a, nullptr, 0, nullptr, out, batch, ws, ws_bytes, stream);
+  int st = check_forward_args(h, x, a, out, batch, ws, ws_bytes);
+  if (st != CASYNC_OK) return st;
+  return run_forward(h, FwdArgs{x, a, nullptr, 0, nullptr, out, batch, ws}, (hipStream_t)stream, nullptr);
 }
 
 int casync_forward_windows(casync_handle h, const float* x, const float* features, int n_steps,
@@ -691,54 +915,9 @@ int casync_forward_windows(casync_handle h, const float* x, const float* feature
                            casync_stream stream) {
   CASYNC_REQUIRE(features && frame_idx && n_steps > 0, "forward_windows: null features / indices");
   CASYNC_REQUIRE(((uintptr_t)features % 16) == 0, "forward_windows: features must be 16-B aligned");
-  return forward_impl(h, x, features, features, n_steps, frame_idx, out, batch, ws, ws_bytes, stream);
-}
-
-static int forward_impl(casync_handle h, const float* x, const float* a, const float* feat, int n_steps,
-                        const int* idx, float* out, int batch, void* ws, int64_t ws_bytes,
-                        casync_stream stream) {
-  int st = check_forward_args(h, x, a, out, batch, ws, ws_bytes);
+  int st = check_forward_args(h, x, features, out, batch, ws, ws_bytes);
   if (st != CASYNC_OK) return st;
-  hipStream_t caller = (hipStream_t)stream;
-  const bool overlap = env_int("CASYNC_OVERLAP", 1) != 0;
-  int lanes = env_int("CASYNC_LANES", 2);
-  lanes = lanes < 1 ? 1 : (lanes > casync_engine::kMaxLanes ? casync_engine::kMaxLanes : lanes);
-  if (batch < kMinLaneBatch * lanes) lanes = 1;  // small batches are latency-bound: cutting them only adds launches
-  if (overlap || lanes > 1) {
-    st = ensure_streams(h);
-    if (st != CASYNC_OK) return st;
-  }
-  if (lanes > 1) CASYNC_CHECK_HIP(hipEventRecord(h->ev_start, caller));
-  int b0 = 0;
-  for (int l = 0; l < lanes; ++l) {
-    const int bl = batch / lanes + (l < batch % lanes ? 1 : 0);
-    Runner r;
-    r.s = l == 0 ? caller : h->lane_s[l];
-    if (l) CASYNC_CHECK_HIP(hipStreamWaitEvent(r.s, h->ev_start, 0));
-    Plan p{*h, Arena(), r, bl};
-    p.lane = l;
-    p.stream_k = lanes == 1;
-    p.concurrent = lanes > 1;
-    p.ar.bind(ws, batch, dtype_size(h->dtype));
-    p.ar.slice(b0);
-    if (overlap) {
-      p.aux = h->aux[l];
-      p.ev_fork = h->ev_fork[l];
-      p.ev_join = h->ev_join[l];
-    }
-    if (feat) {
-      p.win_feat = feat;
-      p.win_steps = n_steps;
-      p.win_idx = idx + b0;
-    }
-    p.forward(x + (size_t)b0 * 6 * 160 * 160, feat ? nullptr : a + (size_t)b0 * 32 * 32 * 32,
-              out + (size_t)b0 * 3 * 160 * 160);
-    if (r.status != CASYNC_OK) return r.status;
-    if (l) CASYNC_CHECK_HIP(hipEventRecord(h->ev_done[l], r.s));
-    b0 += bl;
-  }
-  for (int l = 1; l < lanes; ++l) CASYNC_CHECK_HIP(hipStreamWaitEvent(caller, h->ev_done[l], 0));
-  return CASYNC_OK;
+  return run_forward(h, FwdArgs{x, nullptr, features, n_steps, frame_idx, out, batch, ws}, (hipStream_t)stream, nullptr);
 }
 
 int casync_profile_forward(casync_handle h, const float* x, const float* a, float* out, int batch,
@@ -747,36 +926,18 @@ int casync_profile_forward(casync_handle h, const float* x, const float* a, floa
   int st = check_forward_args(h, x, a, out, batch, ws, ws_bytes);
   if (st != CASYNC_OK) return st;
   CASYNC_REQUIRE(res && cap > 0, "profile_forward: null result buffer");
-  // Same launches (same per-lane sub-batches, hence the same kernel instances and grids) as
-  // casync_forward, but serialised on the caller's stream with an event pair around each.
-  int lanes = env_int("CASYNC_LANES", 2);
-  lanes = lanes < 1 ? 1 : (lanes > casync_engine::kMaxLanes ? casync_engine::kMaxLanes : lanes);
-  if (batch < kMinLaneBatch * lanes) lanes = 1;
-  int n = 0, b0 = 0;
-  for (int l = 0; l < lanes; ++l) {
-    const int bl = batch / lanes + (l < batch % lanes ? 1 : 0);
-    Runner r;
-    r.s = (hipStream_t)stream;
-    r.profile = true;
-    Plan p{*h, Arena(), r, bl};
-    p.lane = l;
-    p.stream_k = lanes == 1;
-    p.concurrent = lanes > 1;
-    p.ar.bind(ws, batch, dtype_size(h->dtype));
-    p.ar.slice(b0);
-    p.forward(x + (size_t)b0 * 6 * 160 * 160, a + (size_t)b0 * 32 * 32 * 32, out + (size_t)b0 * 3 * 160 * 160);
-    r.finish();
-    if (r.status != CASYNC_OK) return r.status;
-    for (size_t i = 0; i < r.rec.size() && n < cap; ++i) res[n++] = r.rec[i];
-    b0 += bl;
-  }
+  std::vector<casync_kernel_time> rec;
+  st = run_forward(h, FwdArgs{x, a, nullptr, 0, nullptr, out, batch, ws}, (hipStream_t)stream, &rec);
+  if (st != CASYNC_OK) return st;
+  int n = 0;
+  for (size_t i = 0; i < rec.size() && n < cap; ++i) res[n++] = rec[i];
   return n;
 }
 
 int64_t casync_tap(casync_handle h, const char* name, int batch, void* ws, void* dst, int64_t dst_floats,
                    casync_stream stream) {
   CASYNC_REQUIRE(h && name && ws && dst && batch > 0, "tap: bad args");
-  Arena ar;
+  Arena ar(h->opt);
   ar.bind(ws, batch, dtype_size(h->dtype));
   using A = Arena;
   struct T { const char* n; Ptr p; int ld, c, rows; };
@@ -832,9 +993,11 @@ int casync_op_pw_gemm(const void* a, int lda, const void* w, const float* bias, 
   // stream-K scratch for the standalone operator: one region per device, created on first use
   // (callers of the op API run one GEMM at a time per device)
   static char* scratch[64] = {};
+  static std::mutex scratch_mu;
   int dev = 0;
   CASYNC_CHECK_HIP(hipGetDevice(&dev));
   if (dev >= 0 && dev < 64) {
+    std::lock_guard<std::mutex> lock(scratch_mu);
     if (!scratch[dev]) {
       CASYNC_CHECK_HIP(hipMalloc((void**)&scratch[dev], kStreamKBytes));
       CASYNC_CHECK_HIP(hipMemset(scratch[dev], 0, kStreamKBytes));

@@ -260,10 +260,7 @@ __global__ __launch_bounds__(64 * WM * WN) void pw_gemm_kernel(const T* __restri
 // one per CU, so the last round costs remainder/256 of a tile time instead of a whole one
 // (M = 6400 rows leave 78-89 % of a round empty otherwise; measured 83 -> 105 TFLOP/s class).
 struct StreamKSplit { long long dp_tiles; int wgs, per; };
-inline int stream_k_mode() {   // read per launch: CASYNC_GEMM_STREAMK=0 gives batch-invariant bits (tests)
-  const char* e = getenv("CASYNC_GEMM_STREAMK");
-  return e && *e ? atoi(e) : 1;
-}
+inline int stream_k_mode() { return casync_opts().gemm_streamk; }   // 0 gives batch-invariant bits (tests)
 inline StreamKSplit stream_k_split(long long tiles, int nk, int tile_floats, bool have_scratch) {
   StreamKSplit s{tiles, 0, 0};
   const long long rem = tiles % kStreamKWgs;
@@ -544,13 +541,9 @@ template <typename T, int BM, int BN, int WM, int WN, int NST, bool CONV = false
 int launch_glds_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, int k,
                   const GemmEpilogue& epi, hipStream_t stream, bool use_sk) {
   constexpr size_t lds = (size_t)NST * (BM + BN) * ROWB;
-  static bool attr_set = false;
+  static unsigned long long attr_once = 0;
   auto kern = pw_gemm_glds_kernel<T, BM, BN, WM, WN, NST, CONV>;
-  if (!attr_set) {
-    CASYNC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)lds)) return st;
   const int n_mtiles = (m + BM - 1) / BM, n_ntiles = n / BN;
   const long long nwg = (long long)n_mtiles * n_ntiles;
   CASYNC_REQUIRE(nwg < (1ll << 31), "gemm grid too large");
@@ -569,18 +562,14 @@ template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, int k,
                  const GemmEpilogue& epi, hipStream_t stream) {
   constexpr size_t lds = gemm_lds_bytes<BM, BN>();
-  static bool attr_set = false;
+  static unsigned long long attr_once = 0;
   auto kern = pw_gemm_kernel<T, BM, BN, WM, WN>;
-  if (!attr_set) {
-    CASYNC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)lds)) return st;
   const int n_mtiles = (m + BM - 1) / BM, n_ntiles = n / BN;
   const long long nwg = (long long)n_mtiles * n_ntiles;
   CASYNC_REQUIRE(nwg < (1ll << 31), "gemm grid too large");
   // persistent grid: as many workgroups as can be resident (LDS-limited), each walks tiles
-  static const int persist = [] { const char* v = getenv("CASYNC_GEMM_PERSIST"); return v ? atoi(v) : 1; }();
+  const int persist = casync_opts().gemm_persist;
   constexpr int per_cu = (int)(160 * 1024 / lds) < 8 ? (int)(160 * 1024 / lds) : 8;
   const long long cap = 256ll * (per_cu < 1 ? 1 : per_cu);
   const unsigned grid = (unsigned)(persist && nwg > cap ? cap : nwg);
@@ -590,10 +579,8 @@ int launch_cfg_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, i
   return CASYNC_OK;
 }
 
-inline int glds_mode() {
-  static const int v = [] { const char* e = getenv("CASYNC_GEMM_GLDS"); return e ? atoi(e) : 2; }();
-  return v;   // 0 = register-staged kernel only, 1 = LDS-DMA ring for bf16, 2 = for both types (default)
-}
+// 0 = register-staged kernel only, 1 = LDS-DMA ring for bf16, 2 = for both types (default)
+inline int glds_mode() { return casync_opts().gemm_glds; }
 
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, int n, int k,
@@ -641,7 +628,7 @@ bool takes_ring(const TileCfg& t, long long tiles, int dtype) {
 }
 
 int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullptr, bool concurrent = false) {
-  static const int forced = [] { const char* v = getenv("CASYNC_GEMM_CFG"); return v ? atoi(v) : -1; }();
+  const int forced = casync_opts().gemm_cfg;
   const int nk = k / (ROWB / dtype_size(dtype));
   if (use_sk) *use_sk = false;
   if (forced >= 0 && forced < CFG_COUNT && n % kTiles[forced].bn == 0) {
@@ -656,8 +643,7 @@ int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullp
   // +600 is the worse operand reuse of small tiles.  Stream-K makes the last round fractional
   // and adds ~5 us (64x64) to ~10 us (128x64) of short-run start-up, parking and fix-up (priced
   // a little higher here so that it is only chosen where it clearly wins).
-  static const int conc_mode = [] { const char* e = getenv("CASYNC_GEMM_CONC"); return e && *e ? atoi(e) : 3; }();
-  static const int conc_tiles = [] { const char* e = getenv("CASYNC_GEMM_CONC_TILES"); return e && *e ? atoi(e) : 2048; }();
+  const int conc_mode = casync_opts().gemm_conc, conc_tiles = casync_opts().gemm_conc_tiles;
   const long long t64 = (long long)((m + 63) / 64) * (n / 64);
   int best = -1;
   double best_cost = 0;
@@ -757,11 +743,11 @@ int launch_conv_t(const T* in, const T* w, T* out, int ldc, int m, int n, int k,
 }  // namespace
 
 const char* conv3x3_gemm_kernel_name(int batch, int h, int wdt, int cin, int cout, int stride, int pad, int dtype,
-                                     bool concurrent) {
+                                     bool concurrent, bool stream_k) {
   static thread_local char buf[64];
   const int ho = (h + 2 * pad - 3) / stride + 1, wo = (wdt + 2 * pad - 3) / stride + 1;
   const int m = batch * ho * wo;
-  const int cfg = pick_cfg(m, cout, 9 * cin, false, dtype, nullptr, concurrent);
+  const int cfg = pick_cfg(m, cout, 9 * cin, stream_k, dtype, nullptr, concurrent);   // the launch's own choice
   const bool small = cfg == C64x64 || cout % 64 || m <= 4096;
   snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, 2, 2, 2, true>", dtype == DT_BF16 ? "__bf16" : "float",
            small ? "64, 64" : "128, 64");

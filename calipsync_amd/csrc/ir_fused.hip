@@ -678,12 +678,8 @@ int launch_inst_b(const bf16_t* lo, int ld_lo, int c_lo, const bf16_t* in, int l
   using G = typename GB::G;
   constexpr size_t lds = (size_t)GB::total;
   auto kern = ir_fused_bf16_kernel<CIN, CE, COUT, STRIDE, UPS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    CASYNC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  static unsigned long long attr_once = 0;
+  if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)lds)) return st;
   const int ho = (h + 2 - 3) / STRIDE + 1, wo = (w + 2 - 3) / STRIDE + 1;
   dim3 grid((wo + TW - 1) / TW, (ho + G::TH - 1) / G::TH, batch);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2,
@@ -699,12 +695,8 @@ int launch_inst_t(const T* lo, int ld_lo, int c_lo, const T* in, int ld_in, cons
   using G = IRGeom<CIN, COUT, STRIDE, CC>;
   constexpr size_t lds = (size_t)G::total * sizeof(float);
   auto kern = ir_fused_kernel<T, CIN, CE, COUT, STRIDE, CC, UPS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    CASYNC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  static unsigned long long attr_once = 0;
+  if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)lds)) return st;
   const int ho = (h + 2 - 3) / STRIDE + 1, wo = (w + 2 - 3) / STRIDE + 1;
   dim3 grid((wo + TW - 1) / TW, (ho + G::TH - 1) / G::TH, batch);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2,

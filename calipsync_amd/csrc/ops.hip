@@ -227,29 +227,54 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 // Reference: FrameSynthesizer._get_audio_features (infer_api.py:99-145): for video frame index i
 // the window is features[i-8 : i+8] of the [T, 2, 1024] HuBERT array, zero-padded past either
 // end, flattened and reshaped to (32, 32, 32) = [c][y][x].  Flat position f = c*1024 + y*32 + x
-// lies in window entry f/2048, half (f%2048)/1024, so channel c = 2*entry + half and pixel
-// p = f%1024:  audio[b][c][p] = features[idx[b] - 8 + c/2][c%2][p].  This writes the engine's NHWC
-// audio input [B][1024][32] directly, so neither the B x 128 KB host windows nor the NCHW->NHWC
-// pass exist.  Thread = (b, p, 4 channels).
+// lies in window row f/2048, half (f%2048)/1024, so channel c = 2*row + half and pixel
+// p = f%1024:  audio[b][c][p] = window[c/2][c%2][p].  This writes the engine's NHWC audio input
+// [B][1024][32] directly, so neither the B x 128 KB host windows nor the NCHW->NHWC pass exist.
+//
+// The reference's corner cases are reproduced exactly (infer_api.py:116-135):
+//   left = i-8, right = i+8; pad_left = max(0,-left), left = max(left,0); pad_right = max(0,right-T),
+//   right = min(right,T); auds = features[left:right]  (Python slice: a negative `right`, possible only
+//   for i < -8, counts from the end); the pads are zeros_like(auds[:pad]), i.e. TRUNCATED to the rows
+//   auds has at that point; the window is used only if it then has exactly 16 rows (numel >= 32768 and
+//   the reshape succeeds), otherwise the frame gets the all-zero default window (:106,141-142).
+// So row r of a valid window is: zero for r < pl, features[start + r - pl] for r < pl + n0, zero after.
+struct AudioWindow { int start, n0, pl, ok; };
+__host__ __device__ inline AudioWindow audio_window_plan(int idx, int T) {
+  const int left0 = idx - 8, right0 = idx + 8;
+  const int pad_left = left0 < 0 ? -left0 : 0, pad_right = right0 > T ? right0 - T : 0;
+  const int left = left0 < 0 ? 0 : left0, right = right0 > T ? T : right0;
+  const int start = left < T ? left : T;                             // slice start (left >= 0)
+  int stop = right >= 0 ? right : (T + right > 0 ? T + right : 0);   // Python semantics of a negative stop
+  stop = stop < T ? stop : T;
+  const int n0 = stop > start ? stop - start : 0;
+  const int pl = pad_left < n0 ? pad_left : n0;                      // zeros_like(auds[:pad_left])
+  const int n1 = n0 + pl;
+  const int pr = pad_right < n1 ? pad_right : n1;                    // zeros_like(auds[:pad_right])
+  return AudioWindow{start, n0, pl, n1 + pr == 16};
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void audio_window_gather_kernel(const float* __restrict__ feat, int n_steps,
                                                                   const int* __restrict__ idx,
                                                                   T* __restrict__ out, long long total) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // thread = (b, p, 4 channels)
   if (i >= total) return;
   const int p = (int)(i % 1024);
   long long t = i / 1024;
   const int c = (int)(t % 8) * 4;
   const int b = (int)(t / 8);
-  const int t0 = idx[b] - 8 + c / 2;   // c is a multiple of 4: entries t0 (c, c+1) and t0+1 (c+2, c+3)
+  const AudioWindow w = audio_window_plan(idx[b], n_steps);
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (t0 >= 0 && t0 < n_steps) {
-    v.x = feat[(size_t)t0 * 2048 + p];
-    v.y = feat[(size_t)t0 * 2048 + 1024 + p];
-  }
-  if (t0 + 1 >= 0 && t0 + 1 < n_steps) {
-    v.z = feat[(size_t)(t0 + 1) * 2048 + p];
-    v.w = feat[(size_t)(t0 + 1) * 2048 + 1024 + p];
+  if (w.ok) {
+    const int r0 = c / 2 - w.pl, r1 = r0 + 1;   // c is a multiple of 4: window rows c/2 (c, c+1) and c/2+1 (c+2, c+3)
+    if (r0 >= 0 && r0 < w.n0) {
+      v.x = feat[(size_t)(w.start + r0) * 2048 + p];
+      v.y = feat[(size_t)(w.start + r0) * 2048 + 1024 + p];
+    }
+    if (r1 >= 0 && r1 < w.n0) {
+      v.z = feat[(size_t)(w.start + r1) * 2048 + p];
+      v.w = feat[(size_t)(w.start + r1) * 2048 + 1024 + p];
+    }
   }
   st4(out + ((size_t)b * 1024 + p) * 32 + c, v);
 }
@@ -405,12 +430,9 @@ inline unsigned blocks_for(long long total) { return (unsigned)((total + 255) / 
 
 // LDS-slab depthwise kernel for this shape?  Slab = 16 (narrow frames) or 8 16-B channel groups
 // wide, as many rows as keep it <= 64 KB, rows split evenly.
-static int lds_budget() {
-  static const int v = [] { const char* e = getenv("CASYNC_DW_LDS_BYTES"); return e && *e ? atoi(e) : 32768; }();
-  return v;
-}
+static int lds_budget() { return casync_opts().dw_lds_bytes; }
 static bool dw_lds_plan(int h, int wdt, int c, int stride, int dtype, int* csv, int* th, int* nt) {
-  static const int enabled = [] { const char* e = getenv("CASYNC_DW_LDS"); return e && *e ? atoi(e) : 1; }();
+  const int enabled = casync_opts().dw_lds;
   if (!enabled || stride != 1 || wdt > 48) return false;
   const int groups = c / (16 / dtype_size(dtype));
   *csv = (wdt <= 12 && groups % 16 == 0) ? 16 : 8;   // 64-B slabs (half an L2 line per pixel) measured 25 % slower

@@ -99,6 +99,10 @@ def fold(sd: Mapping) -> Dict[str, np.ndarray]:
         out[f"{p}.p1.b"] = _np64(sd[f"{p}.attention_adjust_p_1.bias"])
         out[f"{p}.q.w"] = _np64(sd[f"{ca}.query_conv.weight"]).reshape(64, 512)
         out[f"{p}.q.b"] = _np64(sd[f"{ca}.query_conv.bias"])
+        # q = query_conv(p_1(x)) = (Wq Wp1) x + (Wq bp1 + bq): composed in float64, so the query
+        # projection is 64 extra output columns of the p_1 GEMM (module/unet.py:201,209,256,264)
+        out[f"{p}.p1q.w"] = np.concatenate([out[f"{p}.p1.w"], out[f"{p}.q.w"] @ out[f"{p}.p1.w"]], 0)
+        out[f"{p}.p1q.b"] = np.concatenate([out[f"{p}.p1.b"], out[f"{p}.q.w"] @ out[f"{p}.p1.b"] + out[f"{p}.q.b"]])
         out[f"{p}.gamma"] = _np64(sd[f"{ca}.gamma"]).reshape(1)
         sb, tb = _bn_affine(sd, f"{p}.bn")
         out[f"{p}.b1.w"] = _np64(sd[f"{p}.attention_adjust_b_1.weight"]).reshape(1024, 512) * sb[:, None]

@@ -95,7 +95,8 @@ class Model(nn.Module):
         self._engine: Optional[int] = None          # casync_handle
         self._engine_device: Optional[torch.device] = None
         self._packed: Optional[torch.Tensor] = None  # packed weights on the device
-        self._workspace: Dict[int, torch.Tensor] = {}
+        self._workspace: Optional[torch.Tensor] = None   # the largest arena any forward needed so far
+        self._options: Dict[str, int] = {}           # per-engine switches (casync_set_option), re-applied on rebuild
         self.eval()
 
     # ------------------------------------------------------------------ weights
@@ -110,7 +111,7 @@ class Model(nn.Module):
     def _apply(self, fn, recurse=True):
         res = super()._apply(fn, recurse)
         self._invalidate()
-        self._workspace.clear()
+        self._workspace = None
         return res
 
     @property
@@ -127,8 +128,22 @@ class Model(nn.Module):
             if self._engine is not None:
                 _lib.load().casync_destroy(self._engine)
             self._engine, self._packed = None, None
-            self._workspace.clear()
+            self._workspace = None
         return self
+
+    def set_option(self, name: str, value: int) -> "Model":
+        """Engine switch by name for THIS model (``casync_set_option``: "lanes", "trunk_lanes", "overlap",
+        "gemm_streamk", "fuse_ir", "fuse_q", ... -- DESIGN.md section 4).  The CASYNC_* environment only sets
+        the process defaults, once; this is how tests and tools A/B a switch at run time."""
+        self._options[name] = int(value)
+        if self._engine is not None:
+            _lib.set_option(name, value, self._engine)
+        return self
+
+    def get_option(self, name: str) -> int:
+        if self._engine is not None:
+            return _lib.get_option(name, self._engine)
+        return self._options.get(name, _lib.get_option(name))
 
     def refresh_weights(self) -> None:
         """Re-fold and re-upload after parameters were changed in place."""
@@ -146,6 +161,8 @@ class Model(nn.Module):
             _lib.check(lib.casync_create_ex(dev.index or 0, self._dtype, C.byref(h)), "casync_create_ex")
             self._engine, self._engine_device = h, dev
             self._packed = None
+            for name, value in self._options.items():
+                _lib.set_option(name, value, h)
 
     def packed_weights_host(self) -> np.ndarray:
         """BN-folded flat fp32 buffer (engine layout) from the current parameters."""
@@ -157,12 +174,12 @@ class Model(nn.Module):
         dev = packed_dev.device
         if dev.type != "cuda":
             raise RuntimeError("packed weights must live on a ROCm device")
-        self._ensure_engine(dev)
-        lib = _lib.load()
         if packed_dev.dtype != torch.float32 or not packed_dev.is_contiguous():
             raise ValueError("packed weights must be contiguous float32")
-        _lib.check(lib.casync_load_weights_device(self._engine, packed_dev.data_ptr(), packed_dev.numel()),
-                   "casync_load_weights_device")
+        with torch.cuda.device(dev):
+            self._ensure_engine(dev)
+            _lib.check(_lib.load().casync_load_weights_device(self._engine, packed_dev.data_ptr(),
+                                                              packed_dev.numel()), "casync_load_weights_device")
         self._packed = packed_dev
 
     def _ensure_weights(self, dev: torch.device) -> None:
@@ -172,14 +189,15 @@ class Model(nn.Module):
             self.adopt_packed(host.to(dev))
 
     def _ws(self, batch: int, dev: torch.device) -> torch.Tensor:
-        ws = self._workspace.get(batch)
-        if ws is None or ws.device != dev:
-            nbytes = _lib.load().casync_workspace_bytes_dt(batch, self._dtype)
-            # keep only the largest arena: smaller batches could reuse it, but the
-            # arena is bound per batch size, so cache per size and drop the rest
-            self._workspace.clear()
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            self._workspace[batch] = ws
+        """Workspace arena for `batch` frames: any arena at least as large as the engine asks for works
+        (include/casync_hip.h), so the largest one ever needed is kept and reused by smaller batches
+        (the last batch of a clip is smaller, infer_api.py:385-386) instead of reallocating."""
+        need = _lib.load().casync_workspace_bytes_h(self._engine, batch)
+        ws = self._workspace
+        if ws is None or ws.device != dev or ws.numel() < need:
+            self._workspace = None          # release the old arena before taking the bigger one
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._workspace = ws
         return ws
 
     # ------------------------------------------------------------------ forward
@@ -228,7 +246,9 @@ class Model(nn.Module):
         (uploaded once); ``frame_indices``: the video frame index of every batch entry.  Entry b
         sees ``features[i-8:i+8]`` zero-padded past both ends and reshaped to ``(32,32,32)`` --
         the window ``FrameSynthesizer._get_audio_features`` (reference infer_api.py:99-145)
-        builds on the host, bit for bit.  Equivalent to ``forward(x, windows)``."""
+        builds on the host, bit for bit, including its corner cases (a clip shorter than the pad, an
+        index past the end or negative: the reference's truncated ``zeros_like`` pads then miss 16 rows
+        and it falls back to an all-zero window).  Equivalent to ``forward(x, windows)``."""
         dev = self._device()
         if dev.type != "cuda":
             raise RuntimeError("casync_amd.Model runs on a ROCm device only (no CPU fallback)")
@@ -262,7 +282,9 @@ class Model(nn.Module):
     def tap(self, name: str, batch: int) -> torch.Tensor:
         """NCHW copy of a named intermediate of the last forward at this batch size."""
         dev = self._device()
-        ws = self._workspace[batch]
+        ws = self._workspace
+        if ws is None:
+            raise RuntimeError("tap: no forward has run yet")
         lib = _lib.load()
         probe = torch.empty(batch * 160 * 160 * 32, dtype=torch.bfloat16 if self._dtype else torch.float32,
                             device=dev)

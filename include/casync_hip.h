@@ -41,6 +41,9 @@ enum {
 };
 
 /* ---- introspection (callable without a GPU) --------------------------- */
+/* Bumped on every change of a prototype, struct layout or the packed-weight layout; the ctypes
+ * host (calipsync_amd/_lib.py) refuses a library whose version differs from the one it binds.   */
+#define CASYNC_ABI_VERSION 2
 int         casync_abi_version(void);
 const char* casync_last_error(void);           /* thread-local message         */
 
@@ -57,6 +60,19 @@ int64_t     casync_packed_total(void);          /* floats in the whole buffer  *
 /* Workspace (activations, NHWC fp32) needed for a batch of B frames.        */
 int64_t     casync_workspace_bytes(int batch);               /* fp32 engine            */
 int64_t     casync_workspace_bytes_dt(int batch, int dtype); /* 0 = fp32, 1 = bf16     */
+/* ... for THIS handle (its dtype and options: the arena is smaller when the fused kernels are on,
+ * which is the default).  Any arena at least this large is accepted by casync_forward.          */
+int64_t     casync_workspace_bytes_h(casync_handle h, int batch);
+
+/* ---- tuning options ---------------------------------------------------- */
+/* Every switch of the engine by name (the CASYNC_<NAME> environment variables, lower case without
+ * the prefix: "lanes", "trunk_lanes", "overlap", "gemm_streamk", "fuse_ir", "fuse_q", ... -- DESIGN.md
+ * lists them).  The environment is read ONCE per process; casync_create copies the process defaults
+ * into the handle.  h != NULL changes that handle only; h == NULL changes the process defaults, which
+ * the casync_op_* single-operator calls and handles created later use.  No counterpart in the
+ * reference (it has no tuning surface).                                                         */
+int  casync_set_option(casync_handle h, const char* name, int value);
+int  casync_get_option(casync_handle h, const char* name, int* value);
 
 /* ---- engine life cycle ------------------------------------------------- */
 /* Replaces Model(6,"hubert").to(device) (infer_api.py:41).                   */

@@ -1,36 +1,65 @@
-"""CPU restatement of the frame loop's audio-window builder -- TEST INFRASTRUCTURE ONLY.
+"""CPU restatement of the frame loop's tensor glue around the model call -- TEST INFRASTRUCTURE ONLY.
 
-Reference: ``FrameSynthesizer._get_audio_features``
-(image_infer_v1/tools/frame_synthesizer/infer_api.py:99-145).  Pure indexing, so parity
-is bit-exact.  The reference module itself cannot be imported here (``import cv2`` at its top,
-cv2 absent), so this restatement is pinned by reading the source only; the arithmetic it does
-(slice, zero-pad, reshape) has no rounding, and the property tests in
-``tests/test_frame_loop.py`` check it from both ends (padding, interior, ordering)."""
+Reference: ``FrameSynthesizer._get_audio_features`` and the model-input / prediction conversions of
+``process_batch`` (image_infer_v1/tools/frame_synthesizer/infer_api.py:99-145, 238-245, 265-266).
+Pure indexing (+ one IEEE division / multiplication), so parity is bit-exact.
+
+PARITY UNPINNED in the strict sense: the reference module cannot be imported here (``import cv2`` at its
+top, cv2 absent), so these functions are pinned by reading the source only.  ``get_audio_features``
+restates the reference statement by statement (same slicing, same truncated ``zeros_like`` pads, same
+"reshape or fall back to zeros" rule) so that even its never-hit corners -- a clip shorter than the pad, an
+index past the end, a negative index whose ``right`` becomes a from-the-end Python slice -- come out as the
+reference's own numpy/torch expressions would; ``audio_window_plan`` is the closed form of the same rule
+that the HIP kernel implements, and ``tests/test_frame_loop.py`` checks the two against each other over an
+exhaustive (idx, T) grid."""
 from __future__ import annotations
 
 import numpy as np
 
 
 def get_audio_features(features: np.ndarray, indices) -> np.ndarray:
-    """features [T, 2, 1024] -> windows [len(indices), 32, 32, 32] (fp32)."""
-    out = np.zeros((len(indices), 32, 32, 32), dtype=np.float32)
-    n = features.shape[0]
-    for k, idx in enumerate(indices):
-        left, right = idx - 8, idx + 8                  # infer_api.py:111-112
-        pad_left = -left if left < 0 else 0             # :116-118
-        left = max(left, 0)
-        pad_right = right - n if right > n else 0       # :119-121
-        right = min(right, n)
-        if right <= left:                               # window entirely outside: the reference's
-            continue                                    # reshape fails -> default zeros (:106,141-142)
-        win = features[left:right]
-        if pad_left:
-            win = np.concatenate([np.zeros((pad_left,) + win.shape[1:], win.dtype), win], 0)
-        if pad_right:
-            win = np.concatenate([win, np.zeros((pad_right,) + win.shape[1:], win.dtype)], 0)
-        if win.size >= 32 * 32 * 32:                    # :131-135
-            out[k] = win.reshape(32, 32, 32)
-    return out
+    """features [T, 2, 1024] -> windows [len(indices), 32, 32, 32] (fp32); literal restatement of
+    infer_api.py:99-145 with numpy in place of torch (identical slicing semantics)."""
+    batch = []
+    for idx in indices:
+        default = np.zeros((32, 32, 32), dtype=np.float32)          # :106
+        added = False
+        try:
+            left, right = idx - 8, idx + 8                          # :111-112
+            pad_left = pad_right = 0
+            if left < 0:                                            # :116-118
+                pad_left, left = -left, 0
+            if right > features.shape[0]:                           # :119-121
+                pad_right, right = right - features.shape[0], features.shape[0]
+            auds = features[left:right]                             # :123
+            if pad_left > 0:                                        # :125-126  zeros_like(auds[:pad]) is truncated
+                auds = np.concatenate([np.zeros_like(auds[:pad_left]), auds], 0)
+            if pad_right > 0:                                       # :127-128
+                auds = np.concatenate([auds, np.zeros_like(auds[:pad_right])], 0)
+            if auds.size >= 32 * 32 * 32:                           # :131-135
+                batch.append(auds.reshape(32, 32, 32).astype(np.float32, copy=False))   # raises unless 16 rows
+                added = True
+        except Exception:                                           # :136-138
+            pass
+        if not added:                                               # :141-142
+            batch.append(default)
+    return np.array(batch, dtype=np.float32).reshape(len(batch), 32, 32, 32)
+
+
+def audio_window_plan(idx: int, n_steps: int):
+    """Closed form of the rule above (what audio_window_gather_kernel computes): (start, n0, pl, ok) --
+    a valid window is ``pl`` zero rows, then features[start:start+n0], then zero rows up to 16."""
+    left0, right0 = idx - 8, idx + 8
+    pad_left, pad_right = max(0, -left0), max(0, right0 - n_steps)
+    left, right = max(left0, 0), min(right0, n_steps)
+    start = min(left, n_steps)
+    stop = right if right >= 0 else max(n_steps + right, 0)
+    stop = min(stop, n_steps)
+    n0 = max(0, stop - start)
+    pl = min(pad_left, n0)
+    n1 = n0 + pl
+    pr = min(pad_right, n1)
+    return start, n0, pl, n1 + pr == 16
 
 
 def crops_to_model_input(crops168: np.ndarray) -> np.ndarray:

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_layout(lib):
-    assert lib.casync_abi_version() == 1
+    assert lib.casync_abi_version() == _lib.ABI_VERSION
     items, total = _lib.packed_layout()
     names = [n for n, _, _ in items]
     assert len(names) == len(set(names))
@@ -71,8 +71,26 @@ def test_bn_folding_is_exact_on_one_layer(recipe_sd):
 
 def test_workspace_bytes_scale_with_batch(lib):
     one, many = lib.casync_workspace_bytes(1), lib.casync_workspace_bytes(64)
-    assert 40e6 < one < 80e6 and abs(many / one - 64) < 0.01
+    # 35.1 MB per frame with the fused kernels on (the 2 x 160x160x128 expanded slots are not needed);
+    # 55.9 MB with CASYNC_FUSE_IR=0
+    assert 30e6 < one < 60e6 and abs(many / one - 64) < 0.01
     assert lib.casync_workspace_bytes(0) < 0
+
+
+def test_options_are_named_and_checked(lib):
+    """casync_set_option / casync_get_option on the process defaults (no GPU needed); an unknown name is
+    an error, and the workspace of the unfused plan is larger."""
+    assert _lib.get_option("lanes") >= 1
+    with pytest.raises(RuntimeError):
+        _lib.set_option("no_such_switch", 1)
+    fused = lib.casync_workspace_bytes(8)
+    old = _lib.get_option("fuse_ir")
+    try:
+        _lib.set_option("fuse_ir", 0)
+        assert lib.casync_workspace_bytes(8) > fused + 8 * 15e6
+    finally:
+        _lib.set_option("fuse_ir", old)
+    assert lib.casync_workspace_bytes(8) == fused
 
 
 def test_model_has_reference_checkpoint_format(recipe_sd):
@@ -113,4 +131,4 @@ def test_header_is_c99_and_a_plain_c_host_can_bind_it(lib, tmp_path):
                     os.path.join(REPO, "tests", "c", "abi_host.c"), "-ldl", "-o", str(exe)], check=True)
     out = subprocess.run([str(exe), _lib.lib_path()], check=True, capture_output=True, text=True).stdout
     items, total = _lib.packed_layout()
-    assert f"abi 1 tensors {len(items)} " in out and f"total {total} " in out and "gammas 4" in out
+    assert f"abi {_lib.ABI_VERSION} tensors {len(items)} " in out and f"total {total} " in out and "gammas 4" in out

@@ -1,0 +1,68 @@
+"""-m gpu: the RCCL code path on the one GPU the box has -- init_process_group("nccl", world_size=1),
+the packed-weight broadcast, adopt_packed without a copy, one forward -- and bench.py's own launcher."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from calipsync_amd import recipe
+from calipsync_amd.sharding import broadcast_packed_weights, shard_range
+from calipsync_amd.unet import Model
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_rccl_world1_broadcast_adopt_forward(recipe_sd):
+    """backend "nccl" IS RCCL on ROCm: the same calls bench.py makes per rank at N > 1, in a world of one."""
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        src = Model(6, "hubert").to(dev)
+        src.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe_sd.items()})
+        packed = broadcast_packed_weights(src, dev)
+        # a real collective on the buffer (world 1 short-circuits inside broadcast_packed_weights):
+        dist.broadcast(packed, src=0)
+        t = torch.ones(4, device=dev)
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        assert float(t.sum()) == 4.0
+        net = Model(6, "hubert").to(dev)          # default-init parameters: everything comes from `packed`
+        net.adopt_packed(packed)
+        assert net._packed.data_ptr() == packed.data_ptr()          # adopted, not copied
+        start, count = shard_range(5, 0, 1)
+        x, a = recipe.make_inputs_range(start, count)
+        out = net(torch.from_numpy(x).to(dev), torch.from_numpy(a).to(dev))
+        ref = src(torch.from_numpy(x).to(dev), torch.from_numpy(a).to(dev))
+        assert torch.equal(out, ref)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: two child ranks (sharing the one GPU: gloo rehearsal),
+    one JSON line from rank 0, exit code 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--batch", "16", "--strong-frames", "64", "--no-cpu-baseline"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["world_size"] == 2 and r["config"]["global_batch"] == 32
+    assert r["value"] > 0 and r["config"]["strong_scaling"]["global_batch"] == 64

@@ -28,6 +28,53 @@ def test_far_outside_is_zero():
     assert not w.any()
 
 
+def test_closed_form_window_plan_equals_the_literal_restatement():
+    """The HIP kernel implements `audio_window_plan`; the literal statement-by-statement restatement of
+    infer_api.py:99-145 (truncated zeros_like pads, reshape-or-zeros, Python slice semantics for negative
+    bounds) must give the same window for every (idx, T), including clips shorter than the pad."""
+    for t in list(range(1, 20)) + [33, 40]:
+        f = np.arange(1, t * 2048 + 1, dtype=np.float32).reshape(t, 2, 1024)      # all non-zero, row-identifying
+        idxs = list(range(-30, t + 30))
+        lit = frame_loop_oracle.get_audio_features(f, idxs)
+        for k, idx in enumerate(idxs):
+            start, n0, pl, ok = frame_loop_oracle.audio_window_plan(idx, t)
+            want = np.zeros((16, 2, 1024), np.float32)
+            if ok:
+                want[pl:pl + n0] = f[start:start + n0]
+            assert np.array_equal(lit[k].reshape(16, 2, 1024), want), (t, idx)
+
+
+def test_short_clips_and_far_indices_follow_the_reference_truncation():
+    """with T < 8 the reference's pad is zeros_like(auds[:pad]) -- at most len(auds) rows -- so
+    the window misses 16 rows and the frame falls back to zeros; same for idx > T."""
+    f = _features(5)
+    w = frame_loop_oracle.get_audio_features(f, [0, 2, 9, 12, 4])
+    assert not w[:4].any()                        # 5+5+3 = 13, 5+5+5 = 15, 4+4 = 8, 1+1 = 2 rows: never 16
+    # idx=4: 5 rows + pad_left 4 + pad_right 7 (<= the 9 rows it has by then) = 16 -> a valid window
+    assert not w[4, :8].any() and np.array_equal(w[4, 8], f[0, 0].reshape(32, 32)) and not w[4, 18:].any()
+    f = _features(12)
+    w = frame_loop_oracle.get_audio_features(f, [4, 12, 13, 20])
+    assert np.array_equal(w[0, 8], f[0, 0].reshape(32, 32)) and not w[0, :8].any()   # pad 4 <= 12 rows: fine
+    assert np.array_equal(w[1, 0], f[4, 0].reshape(32, 32)) and not w[1, 16:].any()  # idx == T: pad_right 8 <= 8 rows
+    assert not w[2].any() and not w[3].any()      # idx > T: pad_right 9 > the 7 rows left -> zeros
+
+
+@pytest.mark.gpu
+def test_device_window_gather_corner_cases_match_the_literal_oracle(recipe_sd):
+    """Short clips (T < 8), indices past the end and negative indices through the device gather."""
+    from calipsync_amd import recipe
+    from calipsync_amd.unet import Model
+    net = Model(6, "hubert").to("cuda:0")
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe_sd.items()})
+    for t, idx in ((5, [0, 1, 4, 7, 20]), (9, [-9, -8, -1, 0, 8, 9, 10, 17]), (12, [4, 12, 13, 20, -3]),
+                   (16, [8, 0, 16, 17, 24, 25])):
+        feats = _features(t, seed=t)
+        x, _ = recipe.make_inputs(len(idx))
+        xt = torch.from_numpy(x).cuda()
+        host = torch.from_numpy(frame_loop_oracle.get_audio_features(feats, idx)).cuda()
+        assert torch.equal(net.forward_windows(xt, torch.from_numpy(feats).cuda(), idx), net(xt, host)), (t, idx)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_device_window_gather_matches_host_windows(recipe_sd, precision):

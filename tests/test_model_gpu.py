@@ -9,6 +9,7 @@ import torch
 from calipsync_amd import recipe
 from calipsync_amd.unet import Model
 from conftest import sample_indices
+from gpu_util import options
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3          # north-star bar
@@ -65,7 +66,7 @@ def test_against_oracle(net, recipe_sd, batch):
     assert d < TOL and d < EXPECT
 
 
-def test_frames_independent_and_batch_invariant(net, monkeypatch):
+def test_frames_independent_and_batch_invariant(net):
     """A frame's output must not depend on its neighbours or its position in the batch."""
     x, a = recipe.make_inputs(5)
     xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
@@ -74,27 +75,40 @@ def test_frames_independent_and_batch_invariant(net, monkeypatch):
     # stream-K splits a GEMM's k range differently for different row counts: fp32 reassociation only
     assert (full[3:4] - part).abs().max() < 1e-5
     assert torch.equal(net(xt, at), full)            # and it is repeatable bit for bit
-    monkeypatch.setenv("CASYNC_GEMM_STREAMK", "0")   # plain tiles: same order per frame -> bitwise
-    assert torch.equal(net(xt, at)[3:4], net(xt[3:4].contiguous(), at[3:4].contiguous()))
+    with options(net, gemm_streamk=0):               # plain tiles: same order per frame -> bitwise
+        assert torch.equal(net(xt, at)[3:4], net(xt[3:4].contiguous(), at[3:4].contiguous()))
 
 
-def test_lanes_and_stream_overlap_do_not_change_bits(net, monkeypatch):
-    """The batch is cut into concurrent lanes (ragged: 50 = 25 + 25 = 17 + 17 + 16) and the audio
-    branch runs on a side stream; both are scheduling only, so with plain GEMM tiles the output is
-    bit-identical (with stream-K the k-split depends on the lane's row count: checked to 1e-5)."""
+def test_lanes_and_stream_overlap_do_not_change_bits(net):
+    """The batch is cut into concurrent lanes (ragged: 50 = 25 + 25 = 17 + 17 + 16), the 10x10 trunk may
+    run once over the re-joined batch ("hybrid"), and the audio branch runs on a side stream; all of it is
+    scheduling only, so with plain GEMM tiles the output is bit-identical (with stream-K the k-split
+    depends on the row count: checked to 1e-5)."""
     x, a = recipe.make_inputs(50)
     xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
     sk_full = net(xt, at)
-    monkeypatch.setenv("CASYNC_LANES", "1")
-    assert (net(xt, at) - sk_full).abs().max() < 1e-5
-    monkeypatch.setenv("CASYNC_GEMM_STREAMK", "0")
-    monkeypatch.setenv("CASYNC_LANES", "1")
-    monkeypatch.setenv("CASYNC_OVERLAP", "0")
-    base = net(xt, at)
-    for lanes, overlap in (("1", "1"), ("2", "1"), ("3", "1"), ("2", "0")):
-        monkeypatch.setenv("CASYNC_LANES", lanes)
-        monkeypatch.setenv("CASYNC_OVERLAP", overlap)
-        assert torch.equal(net(xt, at), base), (lanes, overlap)
+    with options(net, lanes=1):
+        assert (net(xt, at) - sk_full).abs().max() < 1e-5
+    with options(net, lanes=2, trunk_lanes=1):
+        assert (net(xt, at) - sk_full).abs().max() < 1e-5
+    with options(net, gemm_streamk=0, lanes=1, overlap=0):
+        base = net(xt, at)
+    for lanes, trunk, overlap in ((1, 0, 1), (2, 0, 1), (3, 0, 1), (2, 0, 0), (2, 1, 1), (3, 1, 0)):
+        with options(net, gemm_streamk=0, lanes=lanes, trunk_lanes=trunk, overlap=overlap):
+            assert torch.equal(net(xt, at), base), (lanes, trunk, overlap)
+
+
+def test_fused_query_projection_matches_the_two_gemm_form(net):
+    """q = query_conv(p_1(x)) as 64 extra columns of the p_1 GEMM (weights composed on the host in
+    float64) vs the reference's own two GEMMs: same output to fp32 rounding."""
+    x, a = recipe.make_inputs(3)
+    xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
+    fused = net(xt, at)
+    with options(net, fuse_q=0):
+        two = net(xt, at)
+    d = float((fused - two).abs().max())
+    print("fused q vs two-GEMM q: max|d|", d)
+    assert d < 2e-6
 
 
 def test_audio_matters(net):
@@ -161,18 +175,18 @@ def test_bf16_intermediates_track_fp32(net_bf16, golden, name):
     assert rel < 6e-2
 
 
-def test_bf16_frames_independent(net_bf16, monkeypatch):
+def test_bf16_frames_independent(net_bf16):
     x, a = recipe.make_inputs(5)
     xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
     full = net_bf16(xt, at)
     part = net_bf16(xt[3:4].contiguous(), at[3:4].contiguous())
     assert (full[3:4] - part).abs().max() < 2e-2     # stream-K k-split differs with the row count: bf16 ulps
-    monkeypatch.setenv("CASYNC_GEMM_STREAMK", "0")
-    assert torch.equal(net_bf16(xt, at)[3:4], net_bf16(xt[3:4].contiguous(), at[3:4].contiguous()))
+    with options(net_bf16, gemm_streamk=0):
+        assert torch.equal(net_bf16(xt, at)[3:4], net_bf16(xt[3:4].contiguous(), at[3:4].contiguous()))
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_full_size_batch_properties(recipe_sd, precision, monkeypatch):
+def test_full_size_batch_properties(recipe_sd, precision):
     """BASELINE configs[2]/[3] per-GPU size (512 frames): no oracle run at this size; instead the
     size-independent properties -- every frame equals its own single-frame forward (frames
     independent, lanes / tiling batch-invariant: bit for bit with plain GEMM tiles, to rounding
@@ -191,9 +205,92 @@ def test_full_size_batch_properties(recipe_sd, precision, monkeypatch):
     for i in (0, 7, 15):
         single = m(x[i:i + 1].contiguous(), a[i:i + 1].contiguous())
         assert (single[0] - out[i]).abs().max() < tol, i
-    monkeypatch.setenv("CASYNC_GEMM_STREAMK", "0")
+    m.set_option("gemm_streamk", 0)
     out = m(x, a)
     assert torch.equal(out[:16], out[256:272]) and torch.equal(out[5], out[16 * 31 + 5])
     for i in (0, 7, 15):
         single = m(x[i:i + 1].contiguous(), a[i:i + 1].contiguous())
         assert torch.equal(single[0], out[i]), i
+
+
+# ------------------------------------------------------------------ scheduling edges, caller shapes
+@pytest.mark.parametrize("batch", [31, 32, 33, 63, 65])
+def test_lane_threshold_batches(net, recipe_sd, batch):
+    """Batches on either side of the one-lane / two-lane switch (2 x 16 frames) and of the bench batch:
+    ragged lanes (33 = 17 + 16, 63 = 32 + 31), stream-K vs plain tiles.  Every frame must equal its own
+    single-lane forward to fp32 reassociation, and a sample of frames the CPU oracle."""
+    from oracle import unet_oracle
+    x, a = recipe.make_inputs_range(7, batch)
+    xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
+    out = net(xt, at)
+    assert out.shape == (batch, 3, 160, 160) and torch.isfinite(out).all()
+    with options(net, lanes=1):
+        one = net(xt, at)
+    assert (out - one).abs().max() < 1e-5
+    pick = [0, batch // 2, batch - 1]
+    torch.set_num_threads(16)
+    ref = unet_oracle.forward(unet_oracle.to_torch(recipe_sd), torch.from_numpy(x[pick]), torch.from_numpy(a[pick]))
+    d = float((out[pick].cpu() - ref).abs().max())
+    assert d < TOL and d < EXPECT, d
+
+
+def test_non_contiguous_and_sliced_inputs(net):
+    """The caller may hand over views (a slice of a larger batch, a channels-last / permuted tensor):
+    the result must equal the forward on the contiguous copy, bit for bit."""
+    x, a = recipe.make_inputs(6)
+    xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
+    ref = net(xt[1:5].contiguous(), at[1:5].contiguous())
+    assert torch.equal(net(xt[1:5], at[1:5]), ref)                                  # offset views
+    xs, as_ = xt[::2], at[::2]                                                      # strided batch views
+    assert not xs.is_contiguous()
+    assert torch.equal(net(xs, as_), net(xs.contiguous(), as_.contiguous()))
+    xcl = xt[1:5].contiguous(memory_format=torch.channels_last)                     # NHWC storage, NCHW shape
+    acl = at[1:5].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    assert not xcl.is_contiguous() and not acl.is_contiguous()
+    assert torch.equal(net(xcl, acl), ref)
+
+
+def test_forward_from_a_worker_thread(net, recipe_sd):
+    """The streaming caller runs the model on a threading.Thread (image_infer_v1/infer_api.py:194);
+    hipSetDevice is per thread, so the engine must not assume the main thread.  Also on a non-default
+    torch stream."""
+    import threading
+    x, a = recipe.make_inputs(3)
+    xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
+    ref = net(xt, at)
+    got, err = {}, []
+
+    def work():
+        try:
+            torch.cuda.set_device(0)
+            got["plain"] = net(xt, at)
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                got["stream"] = net(xt, at)
+            s.synchronize()
+            m = Model(6, "hubert").to("cuda:0")              # an engine created on the worker thread
+            m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe_sd.items()})
+            got["fresh"] = m(xt, at)
+            torch.cuda.synchronize()
+        except Exception as exc:                              # surfaced below: a thread must not swallow it
+            err.append(exc)
+
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert not err, err
+    for k in ("plain", "stream", "fresh"):
+        assert torch.equal(got[k], ref), k
+
+
+def test_workspace_is_reused_across_batch_sizes(net):
+    """Variable last batch (infer_api.py:385-386): a smaller batch after a larger one reuses the arena."""
+    x, a = recipe.make_inputs(9)
+    xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
+    big = net(xt, at)
+    ws = net._workspace
+    small = net(xt[:4].contiguous(), at[:4].contiguous())
+    assert net._workspace is ws
+    assert (small - big[:4]).abs().max() < 1e-5
+    assert torch.equal(net(xt, at), big)

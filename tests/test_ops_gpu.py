@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from calipsync_amd import _lib, pack
-from gpu_util import dev, nchw, nhwc, ok, ptr, stream
+from gpu_util import dev, nchw, nhwc, ok, options, ptr, stream
 
 pytestmark = pytest.mark.gpu
 
@@ -58,7 +58,7 @@ def test_pw_gemm_stream_k_remainder(lib, m, n, k):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
 
 
-def test_pw_gemm_stream_k_random_shapes_match_plain_tiles(lib, monkeypatch):
+def test_pw_gemm_stream_k_random_shapes_match_plain_tiles(lib):
     """Stress: 48 random shapes, stream-K on vs off (plain tiles) on the same operands -- equal to fp32
     reassociation, and the stream-K result repeats bit for bit (no arrival-order dependence)."""
     rng = np.random.default_rng(2024)
@@ -72,11 +72,11 @@ def test_pw_gemm_stream_k_random_shapes_match_plain_tiles(lib, monkeypatch):
         wd = (torch.randn(n, k, generator=g) / k ** 0.5).to(dev())
         bd = torch.randn(n, generator=g).to(dev())
         outs = []
-        for sk in ("1", "1", "0"):
-            monkeypatch.setenv("CASYNC_GEMM_STREAMK", sk)
-            c = torch.full((m, n), float("nan"), device=dev())
-            ok(lib.casync_op_pw_gemm(ptr(ad), k, ptr(wd), ptr(bd), ptr(c), n, m, n, k, 1, 0, 0, 0, 0, 0, 0, 0, stream()))
-            outs.append(c)
+        for sk in (1, 1, 0):
+            with options(gemm_streamk=sk):
+                c = torch.full((m, n), float("nan"), device=dev())
+                ok(lib.casync_op_pw_gemm(ptr(ad), k, ptr(wd), ptr(bd), ptr(c), n, m, n, k, 1, 0, 0, 0, 0, 0, 0, 0, stream()))
+                outs.append(c)
         assert torch.equal(outs[0], outs[1]), (m, n, k)
         worst = max(worst, rel_err(outs[0], outs[2]))
     assert worst < 5e-6, worst

@@ -9,7 +9,7 @@ for B in (64,):
     x, a = recipe.make_inputs(B)
     x, a = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
     for lanes in ("1", "2"):
-        os.environ["CASYNC_LANES"] = lanes
+        net.set_option("lanes", int(lanes))
         for _ in range(5): net(x, a)
         torch.cuda.synchronize()
         # enqueue time with an idle GPU queue: sync before each call

@@ -7,7 +7,7 @@ net = Model(6, "hubert").to("cuda:0")
 net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe.make_state_dict().items()})
 x, a = recipe.make_inputs(64)
 x, a = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
-os.environ["CASYNC_LANES"] = "2"
+net.set_option("lanes", 2)
 net(x, a); rows = net.profile(x, a); rows = net.profile(x, a)
 half = len(rows) // 2
 tot = 0

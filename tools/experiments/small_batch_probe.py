@@ -5,7 +5,7 @@ from calipsync_amd.unet import Model
 dev = torch.device("cuda", 0)
 net = Model(6, "hubert").to(dev)
 net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe.make_state_dict().items()})
-os.environ["CASYNC_LANES"] = "1"
+net.set_option("lanes", 1)
 for b in (1, 8):
     x_np, a_np = recipe.make_inputs(b)
     x, a = torch.from_numpy(x_np).to(dev), torch.from_numpy(a_np).to(dev)
@@ -16,7 +16,7 @@ for b in (1, 8):
     for r in top: print(f"   {r['name']:50s} {r['kernel']:48s} {r['ms']*1e3:7.1f} us")
     torch.cuda.synchronize()
     for ov in ("1", "0"):
-        os.environ["CASYNC_OVERLAP"] = ov
+        net.set_option("overlap", int(ov))
         for _ in range(3): net(x, a)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -25,4 +25,4 @@ for b in (1, 8):
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         print(f"   overlap={ov}: host enqueue {1e3*(t1-t0)/100:.3f} ms/forward, total {1e3*(t2-t0)/100:.3f} ms/forward")
-    os.environ["CASYNC_OVERLAP"] = "1"
+    net.set_option("overlap", 1)

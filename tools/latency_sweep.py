@@ -23,7 +23,7 @@ for b in [int(v) for v in args.batches.split(",")]:
     x_np, a_np = recipe.make_inputs(b)
     x, a = torch.from_numpy(x_np).to(dev), torch.from_numpy(a_np).to(dev)
     for lanes in args.lanes.split(","):
-        os.environ["CASYNC_LANES"] = lanes
+        net.set_option("lanes", int(lanes))
         for _ in range(5):
             net(x, a)
         torch.cuda.synchronize()

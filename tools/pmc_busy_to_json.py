@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc passes of tools/collect_pmc_busy.sh -> per-kernel MFMA-busy / stall / LDS figures.
+
+    python tools/pmc_busy_to_json.py <pmc_busy_dir> <out.json>
+
+Per kernel (average over its launches in `bench.py --replay-only`, i.e. the timed run's own launches,
+serialised):
+  kernel_cycles            GRBM_GUI_ACTIVE / 8          (the counter sums the 8 XCDs)
+  cu_busy                  SQ_BUSY_CU_CYCLES / (256 CUs x kernel_cycles): share of the launch a CU has a wave
+  mfma_busy_of_kernel_time SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel_cycles)
+  mfma_busy_of_cu_busy     SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)
+  wait_any / wait_inst_any / wait_inst_lds   shares of SQ_WAVE_CYCLES (parked on s_waitcnt or a barrier /
+                           issue-stalled / issue-stalled on LDS)
+  lds_bank_conflict        SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+Units per MI355X_MICROARCH.md (rocprofv3 PMC slots; SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD)."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def load(d):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(f"{d}/g*/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            name = re.sub(r"\(anonymous namespace\)::|^void |\(.*", "", r["Kernel_Name"]).strip()
+            if name.startswith(("at::", "__amd")) or "elementwise" in name:
+                continue
+            agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"_n": max(len(v) for v in cs.values())} for k, cs in agg.items()}
+
+
+def main():
+    src, out_path = sys.argv[1], sys.argv[2]
+    out = {}
+    for k, c in sorted(load(src).items()):
+        cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        row = {"launches_sampled": int(c["_n"]), "kernel_cycles": round(cyc)}
+        if cyc:
+            row["cu_busy"] = round(c.get("SQ_BUSY_CU_CYCLES", 0.0) / (256 * cyc), 4)
+            row["mfma_busy_of_kernel_time"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * cyc), 4)
+        if c.get("SQ_BUSY_CU_CYCLES"):
+            row["mfma_busy_of_cu_busy"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4 * c["SQ_BUSY_CU_CYCLES"]), 4)
+        if c.get("SQ_WAVE_CYCLES"):
+            for name in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS"):
+                row[name[3:].lower()] = round(c.get(name, 0.0) / c["SQ_WAVE_CYCLES"], 4)
+        if c.get("SQ_LDS_IDX_ACTIVE"):
+            row["lds_bank_conflict"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
+        out[k] = row
+    json.dump({"source": f"profiles/{os.path.basename(out_path)}: rocprofv3 --pmc (SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES "
+                         "GRBM_GUI_ACTIVE | SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS | SQ_LDS_BANK_CONFLICT "
+                         "SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS, one group per pass) of `bench.py --replay-only` "
+                         "(tools/collect_pmc_busy.sh)",
+               "kernels": out}, open(out_path, "w"), indent=1)
+    for k, v in out.items():
+        print(f"{k:58s} n={v['launches_sampled']:4d} cyc={v['kernel_cycles']:8d} cu_busy={v.get('cu_busy', 0):.2f} "
+              f"mfma/kernel={v.get('mfma_busy_of_kernel_time', 0):.2f} mfma/cu_busy={v.get('mfma_busy_of_cu_busy', 0):.2f} "
+              f"wait={v.get('wait_any', 0):.2f} bank={v.get('lds_bank_conflict', 0):.2f}")
+
+
+if __name__ == "__main__":
+    main()
