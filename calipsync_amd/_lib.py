@@ -47,6 +47,7 @@ _PROTOS = {
     "casync_profile_forward": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_void_p,
                                          c_i64, C.c_void_p, C.POINTER(KernelTime), C.c_int]),
     "casync_op_set_dtype": (C.c_int, [C.c_int]),
+    "casync_debug_gemm_stamps": (C.c_int, [C.c_void_p]),
     "casync_op_pw_gemm": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_f32p, c_f32p,
                                     C.c_int, c_f32p, c_f32p, C.c_void_p]),
@@ -69,6 +70,10 @@ _PROTOS = {
                                    C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "casync_op_crop_to_input": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.c_void_p]),
     "casync_op_pred_to_u8": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_void_p]),
+    "casync_frame_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, c_f32p, C.c_void_p]),
+    "casync_frame_paste_back": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_f32p, C.c_void_p, c_f32p, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "casync_op_nchw_to_nhwc": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "casync_op_inc": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_void_p]),
     "casync_op_outc": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_void_p]),

@@ -51,6 +51,7 @@ struct CasyncOptions {
   int gemm_streamk = 1;      // CASYNC_GEMM_STREAMK: stream-K remainders in single-lane runs
   int gemm_glds = 2;         // CASYNC_GEMM_GLDS: LDS-DMA ring GEMM: 0 off, 1 bf16 only, 2 both types
   int gemm_cfg = -1;         // CASYNC_GEMM_CFG: force one tile configuration
+  int gemm_pipe = 3;         // CASYNC_GEMM_PIPE: stages of the software-pipelined LDS-DMA ring, 3..6 (0 = the round-1 loop)
   int gemm_persist = 1;      // CASYNC_GEMM_PERSIST: persistent grid of the register-staged GEMM
   int gemm_conc = 3;         // CASYNC_GEMM_CONC: tile policy when lanes share the chip
   int gemm_conc_tiles = 2048;  // CASYNC_GEMM_CONC_TILES
@@ -62,6 +63,7 @@ struct CasyncOptions {
   int dw_lds_bytes = 32768;  // CASYNC_DW_LDS_BYTES
   int conv_im2col = 0;       // CASYNC_CONV_IM2COL: dense 3x3 via im2col + GEMM instead of the implicit GEMM
   int att_nz = 0;            // CASYNC_ATT_NZ: channel split of the attention kernel (0 = by batch)
+  int dbg_noload = 0;        // CASYNC_DBG_NOLOAD: diagnostic (casync_op_pw_gemm only): no LDS-DMA after the ring is first filled
 };
 CasyncOptions& casync_default_options();      // process defaults (environment read once, thread-safe)
 const CasyncOptions& casync_opts();           // options of the call in progress on this thread
@@ -140,6 +142,8 @@ struct GemmEpilogue {
   // kStreamKCounters zeroed counters, private to the stream the GEMM runs on
   float* sk_ws = nullptr;
   unsigned* sk_cnt = nullptr;
+  unsigned long long* stamps = nullptr;   // diagnostic only: 8 words per workgroup (see pw_gemm_glds_kernel)
+  int dbg_noload = 0;                     // diagnostic only: skip the steady-state LDS-DMA (timing experiment)
   // the launch shares the chip with another lane's kernels (two-lane schedule): tile choice then
   // favours many small workgroups that interleave on a CU over few large ones (see pick_cfg)
   int concurrent = 0;

@@ -968,6 +968,13 @@ int64_t casync_tap(casync_handle h, const char* name, int batch, void* ws, void*
 }
 
 // ---- single operators ------------------------------------------------------
+// diagnostic: device buffer of 8 x grid words that the NEXT casync_op_pw_gemm calls of this thread stamp
+// (null = off).  Not part of the product path.
+static thread_local unsigned long long* g_gemm_stamps = nullptr;
+int casync_debug_gemm_stamps(void* dev_words) {
+  g_gemm_stamps = static_cast<unsigned long long*>(dev_words);
+  return CASYNC_OK;
+}
 static thread_local int g_op_dtype = DT_F32;
 int casync_op_set_dtype(int dtype) {
   CASYNC_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "op_set_dtype: %d", dtype);
@@ -1006,6 +1013,8 @@ int casync_op_pw_gemm(const void* a, int lda, const void* w, const float* bias, 
     e.sk_ws = reinterpret_cast<float*>(scratch[dev]);
     e.sk_cnt = reinterpret_cast<unsigned*>(scratch[dev] + kStreamKFloats * 4);
   }
+  e.stamps = g_gemm_stamps;
+  e.dbg_noload = casync_opts().dbg_noload;
   return launch_pw_gemm(a, lda, w, c, ldc, m, n, k, e, (hipStream_t)stream, g_op_dtype);
 }
 int casync_op_conv3x3(const void* in, const void* w, const float* bias, void* out, int batch, int h, int wdt,

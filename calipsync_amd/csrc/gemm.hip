@@ -28,6 +28,8 @@
 // coalesced row segment, instead of 4-B-per-lane scatter in the MFMA C layout.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -312,8 +314,8 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
   constexpr int LPT = ROWS / 32;              // LDS-DMA instructions per wave per k-tile (8 rows each, 4 waves)
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int LDC_S = BN + 4;
-  static_assert((size_t)NST * STAGE >= (size_t)BM * LDC_S * sizeof(float), "ring must hold the C tile");
-  static_assert(LPT * (NST - 1) < 64, "vmcnt range");
+  static_assert((size_t)NST * STAGE >= (size_t)(BM / WM) * LDC_S * sizeof(float), "ring must hold one wave-row block of C");
+  static_assert(LPT * (NST - 1) < 64, "vmcnt range");   // 6-bit counter
   extern __shared__ __attribute__((aligned(16))) char ring[];
   float* Cs = reinterpret_cast<float*>(ring);
 
@@ -377,7 +379,8 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
         src[j] = W + (size_t)(n0 + r - BM) * K + cs * E16 + (size_t)k0 * BK;
       }
     }
-    auto issue = [&](int kt) {
+    // LDS-DMA pieces [LPT*part/4, LPT*(part+1)/4) of k-tile kt (part 0..3; issue() = all four)
+    auto issue_part = [&](int kt, int part) {
       char* st = ring + (kt % NST) * STAGE;
       [[maybe_unused]] int tap = 0, tap_off = 0;
       if constexpr (CONV) {   // k-tile -> (tap, channel offset): C / BK k-tiles per tap
@@ -385,8 +388,10 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
         tap = kg / kpt;
         tap_off = ((tap / 3) * epi.conv_w + tap % 3) * epi.conv_c + (kg - tap * kpt) * BK;
       }
+      if (epi.dbg_noload && kt >= NST) return;   // timing experiment only (wrong results): no LDS-DMA in the steady loop
 #pragma unroll
       for (int j = 0; j < LPT; ++j) {
+        if (j < LPT * part / 4 || j >= LPT * (part + 1) / 4) continue;
         const T* p;
         if (CONV && j < BM / 32) {   // rows of the A part (compile-time per j: r < BM <=> j < BM/32)
           const int r = (j * 4 + wave) * 8 + lrow8;
@@ -400,11 +405,11 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
                                          16, 0, 0);
       }
     };
-    zero_acc();
+    auto issue = [&](int kt) {
 #pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-      if (s < cnt) issue(s);
-
+      for (int part = 0; part < 4; ++part) issue_part(kt, part);
+    };
+    zero_acc();
     // fragment addressing: row byte offset and swizzle key are loop-invariant per lane
     int a_off[TM], a_key[TM], b_off[TN], b_key[TN];
 #pragma unroll
@@ -419,49 +424,139 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
       b_off[j] = r * ROWB;
       b_key[j] = (r >> 1) & 7;
     }
+    // one 32-B column pair (g) of the tile in stage `st`: the 16 B this lane feeds to four MFMA k-steps
+    auto frag = [&](const char* st, int g, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
+      if (epi.dbg_noload >= 3) return;   // timing experiment without the LDS fragment reads
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const f32x4*>(st + a_off[i] + (((2 * g + kh) ^ a_key[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = *reinterpret_cast<const f32x4*>(st + b_off[j] + (((2 * g + kh) ^ b_key[j]) << 4));
+    };
+    auto mma = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = MfmaK<T>::run(fa[i], fb[j], acc[i][j]);
+    };
 
-    for (int kt = 0; kt < cnt; ++kt) {
-      // tiles kt+1 .. kt+NST-2 may stay in flight (fewer near the end of the k loop)
-      const int ahead = cnt - 1 - kt;
-      if (NST >= 4 && ahead >= 2) wait_vmcnt<(NST >= 4 ? 2 : 0) * LPT>();
-      else if (NST >= 3 && ahead >= 1) wait_vmcnt<LPT>();
-      else wait_vmcnt<0>();
+    if constexpr (NST >= 3) {
+      // Software-pipelined loop over an NST-stage ring.  Invariant behind the barrier at the top of k-tile
+      // kt: tiles kt AND kt+1 have landed for every wave (each wave waited for its own LDS-DMA first:
+      // counted vmcnt, tiles kt+2 .. kt+NST-2 stay in flight), and every wave is done reading the stage of
+      // tile kt-1.  So inside iteration kt
+      //   * the loads of tile kt+NST-1 go into the stage of tile kt-1, issued BETWEEN the MFMA groups (an
+      //     LDS-DMA instruction costs 60-180 issue cycles: in front of the MFMAs that was a bubble),
+      //   * the fragments of the next column pair -- for the last pair: of tile kt+1's first pair, which
+      //     this barrier already covers -- are read while the current pair's MFMAs run,
+      // and the only thing left between two k-tiles' MFMAs is the barrier itself.  A tile has NST-2
+      // iterations to land before it is waited for (an LDS-DMA load takes 1-2.5 us under load, one
+      // iteration 0.4-1.7 us: tools/experiments/gemm_timeline.py).
+      constexpr int AHEAD = NST - 1;            // tiles issued ahead of the one being computed
+#pragma unroll
+      for (int t = 0; t < AHEAD; ++t)
+        if (t < cnt) issue(t);
+      f32x4 fa0[TM] = {}, fb0[TN] = {}, fa1[TM] = {}, fb1[TN] = {};
+      // cold start: tile 0 (and tile 1) landed, the first column pair of tile 0 in registers
+      if (cnt >= AHEAD) wait_vmcnt<(NST - 3) * LPT>(); else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (kt + NST - 1 < cnt) issue(kt + NST - 1);
-      const char* st = ring + (kt % NST) * STAGE;
+      frag(ring, 0, fa0, fb0);
+      // straight-line body (no branches: MORE / NEXT are compile-time), so the scheduler hints below hold
+      // and the waitcnt pass sees one basic block per k-tile
+      constexpr int NM = TM * TN * (sizeof(T) == 4 ? 4 : 1);   // MFMAs per column pair
+      constexpr int ND = TM + TN;                               // ds_read_b128 per column pair
+      auto body = [&](int kt, auto more_c, auto next_c, auto flight_c) {
+        constexpr bool MORE = decltype(more_c)::value, NEXT = decltype(next_c)::value;
+        // tiles <= kt+1 landed; FLIGHT later tiles (kt+2 ...) stay in flight
+        wait_vmcnt<decltype(flight_c)::value * LPT>();
+        if (epi.dbg_noload < 2) __builtin_amdgcn_s_barrier();   // (>= 2: timing experiment without the barrier)
+        asm volatile("" ::: "memory");
+        const char* st = ring + (kt % NST) * STAGE;
+        const char* st_next = ring + ((kt + 1) % NST) * STAGE;
+        frag(st, 1, fa1, fb1);
+        if constexpr (MORE) issue_part(kt + AHEAD, 0);
+        mma(fa0, fb0);
+        frag(st, 2, fa0, fb0);
+        if constexpr (MORE) issue_part(kt + AHEAD, 1);
+        mma(fa1, fb1);
+        frag(st, 3, fa1, fb1);
+        if constexpr (MORE) issue_part(kt + AHEAD, 2);
+        mma(fa0, fb0);
+        if constexpr (NEXT) frag(st_next, 0, fa0, fb0);
+        if constexpr (MORE) issue_part(kt + AHEAD, 3);
+        mma(fa1, fb1);
+        // per column pair: one MFMA (its operands were read a whole pair ago, so the wait in front of it
+        // covers no fresh read), then the next pair's LDS reads, this quarter of the LDS-DMA pieces, the
+        // rest of the MFMAs
+#define CASYNC_GEMM_HINT(G)                                                                                    \
+  do {                                                                                                         \
+    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                                           \
+    if constexpr ((G) < 3 || NEXT) __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);                          \
+    if constexpr (MORE && (LPT * ((G) + 1) / 4 - LPT * (G) / 4) > 0)                                           \
+      __builtin_amdgcn_sched_group_barrier(0x20, LPT * ((G) + 1) / 4 - LPT * (G) / 4, 0);                      \
+    if constexpr (NM > 1) __builtin_amdgcn_sched_group_barrier(0x8, NM - 1, 0);                                \
+  } while (0)
+        CASYNC_GEMM_HINT(0);
+        CASYNC_GEMM_HINT(1);
+        CASYNC_GEMM_HINT(2);
+        CASYNC_GEMM_HINT(3);
+#undef CASYNC_GEMM_HINT
+      };
+      using std::integral_constant;
+      int kt = 0;
+      for (; kt + AHEAD < cnt; ++kt) body(kt, std::true_type{}, std::true_type{}, integral_constant<int, NST - 3>{});
+      // drain: `left` tiles follow kt, all issued; left - 1 of them may stay in flight
+      for (; kt + 1 < cnt; ++kt) {
+        const int left = cnt - 1 - kt;
+        if (NST >= 6 && left >= 4) body(kt, std::false_type{}, std::true_type{}, integral_constant<int, NST >= 6 ? 3 : 0>{});
+        else if (NST >= 5 && left == 3) body(kt, std::false_type{}, std::true_type{}, integral_constant<int, NST >= 5 ? 2 : 0>{});
+        else if (NST >= 4 && left == 2) body(kt, std::false_type{}, std::true_type{}, integral_constant<int, NST >= 4 ? 1 : 0>{});
+        else body(kt, std::false_type{}, std::true_type{}, integral_constant<int, 0>{});
+      }
+      body(kt, std::false_type{}, std::false_type{}, integral_constant<int, 0>{});
+    } else {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 fa[TM], fb[TN];
+      for (int s = 0; s < NST - 1; ++s)
+        if (s < cnt) issue(s);
+      for (int kt = 0; kt < cnt; ++kt) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + NST - 1 < cnt) issue(kt + NST - 1);
+        const char* st = ring + (kt % NST) * STAGE;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-          fa[i] = *reinterpret_cast<const f32x4*>(st + a_off[i] + (((2 * g + kh) ^ a_key[i]) << 4));
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          fb[j] = *reinterpret_cast<const f32x4*>(st + b_off[j] + (((2 * g + kh) ^ b_key[j]) << 4));
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = MfmaK<T>::run(fa[i], fb[j], acc[i][j]);
+        for (int g = 0; g < 4; ++g) {
+          f32x4 fa[TM], fb[TN];
+          frag(st, g, fa, fb);
+          mma(fa, fb);
+        }
       }
     }
     __syncthreads();   // everything landed and consumed: the ring is free (it becomes the C tile)
   };
 
   // acc -> C tile in LDS -> bias / residuals / activation -> coalesced store; ends with the ring idle
+  // One wave-row block (BM / WM rows) at a time, so the staging area is BM / WM x (BN + 4) floats and a
+  // two- or three-stage ring of any tile shape can hold it.
   auto epilogue = [&] {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int h = 0; h < WM; ++h) {
+      if (wm == h) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        float* cbase = Cs + (wm * (BM / WM) + i * 32 + 4 * kh) * LDC_S + wn * (BN / WN) + j * 32 + r32;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cbase[((r & 3) + 8 * (r >> 2)) * LDC_S] = acc[i][j][r];
+          for (int j = 0; j < TN; ++j) {
+            float* cbase = Cs + (i * 32 + 4 * kh) * LDC_S + wn * (BN / WN) + j * 32 + r32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cbase[((r & 3) + 8 * (r >> 2)) * LDC_S] = acc[i][j][r];
+          }
       }
-    __syncthreads();
-
-    epilogue_rows<T, 256, BM, BN>(Cs, m0, n0, M, C, ldc, epi, tid);
-    __syncthreads();   // C tile consumed before the next loads overwrite the ring
+      __syncthreads();
+      epilogue_rows<T, 256, BM / WM, BN>(Cs, m0 + h * (BM / WM), n0, M, C, ldc, epi, tid);
+      __syncthreads();   // staging consumed before the next block / the next loads overwrite the ring
+    }
   };
 
   // ---- stream-K part: the k-iterations of the remaining tiles, cut into sk_wgs equal runs of
@@ -530,10 +625,27 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
   }
 
   // ---- data-parallel part: whole tiles, every workgroup strides over them ----
-  for (int tile = blockIdx.x; tile < dp_tiles; tile += gridDim.x) {
+  // Diagnostic stamps (epi.stamps, null in every product call: tools/experiments/gemm_timeline.py sets
+  // them): 100 MHz wall clock at entry / after the k loop / after the epilogue of each of the first
+  // two tiles, and at exit.
+  auto stamp = [&](int slot) {
+    if (epi.stamps && tid == 0) epi.stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+  };
+  // slot 7: shader-clock cycles (s_memtime) spent between entry and exit -> clock = cycles / (exit - entry)
+  const unsigned long long cyc0 = epi.stamps ? __builtin_amdgcn_s_memtime() : 0;
+  stamp(0);
+  int done = 0;
+  for (int tile = blockIdx.x; tile < dp_tiles; tile += gridDim.x, ++done) {
     tile_origin(tile);
     run_k(0, nk);
+    if (done < 2) stamp(1 + 2 * done);
     epilogue();
+    if (done < 2) stamp(2 + 2 * done);
+  }
+  stamp(5);
+  if (epi.stamps && tid == 0) {
+    epi.stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)done;
+    epi.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - cyc0;
   }
 }
 
@@ -589,21 +701,35 @@ int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, i
   // per CU), 64x64 -> 2 stages (32 KB, five per CU).  Measured every time: one more co-resident
   // workgroup beats one more stage of prefetch (128x64: +1.5 % fp32, +3.6 % bf16 end to end;
   // 64x64 two stages vs three: +0.8 % at B=64, +1.6 % at B=32 in the two-lane schedule).
-  constexpr int NST = (BM + BN) >= 256 ? 3 : 2;
+  constexpr int NST2 = (BM + BN) >= 256 ? 3 : 2;
   // The 128x128 ring leaves room for one workgroup per CU only: use it when the launch has at most
   // one tile per CU anyway (then its deeper pipeline wins), else the register-staged kernel with
   // two co-resident workgroups.  The smaller tiles always take the ring.
   const long long tiles = (long long)((m + BM - 1) / BM) * (n / BN);
-  const bool ring_ok = (BM + BN) < 256 || tiles <= 256;
+  const int pipe = casync_opts().gemm_pipe;   // software-pipelined ring: number of stages (0 = the round-1 loop)
+  const bool ring_ok = pipe != 0 || (BM + BN) < 256 || tiles <= 256;
   if constexpr (WM * WN == 4 && BN >= 64) {
     if (ring_ok && dtype == DT_BF16 && glds_mode() >= 1)
-      return launch_glds_t<bf16_t, BM, BN, WM, WN, NST>(static_cast<const bf16_t*>(a), lda,
-                                                        static_cast<const bf16_t*>(w), static_cast<bf16_t*>(c),
-                                                        ldc, m, n, k, epi, stream, use_sk);
-    if (ring_ok && dtype == DT_F32 && glds_mode() >= 2)
-      return launch_glds_t<float, BM, BN, WM, WN, NST>(static_cast<const float*>(a), lda,
-                                                       static_cast<const float*>(w), static_cast<float*>(c), ldc,
-                                                       m, n, k, epi, stream, use_sk);
+      return pipe ? launch_glds_t<bf16_t, BM, BN, WM, WN, 3>(static_cast<const bf16_t*>(a), lda,
+                                                             static_cast<const bf16_t*>(w), static_cast<bf16_t*>(c),
+                                                             ldc, m, n, k, epi, stream, use_sk)
+                  : launch_glds_t<bf16_t, BM, BN, WM, WN, NST2>(static_cast<const bf16_t*>(a), lda,
+                                                                static_cast<const bf16_t*>(w), static_cast<bf16_t*>(c),
+                                                                ldc, m, n, k, epi, stream, use_sk);
+    if (ring_ok && dtype == DT_F32 && glds_mode() >= 2) {
+      const float* af = static_cast<const float*>(a);
+      const float* wf = static_cast<const float*>(w);
+      float* cf = static_cast<float*>(c);
+      constexpr int STAGE_KB = (BM + BN) * ROWB / 1024;
+      if constexpr (4 * STAGE_KB <= 160)
+        if (pipe == 4) return launch_glds_t<float, BM, BN, WM, WN, 4>(af, lda, wf, cf, ldc, m, n, k, epi, stream, use_sk);
+      if constexpr (5 * STAGE_KB <= 160)
+        if (pipe == 5) return launch_glds_t<float, BM, BN, WM, WN, 5>(af, lda, wf, cf, ldc, m, n, k, epi, stream, use_sk);
+      if constexpr (6 * STAGE_KB <= 160)
+        if (pipe == 6) return launch_glds_t<float, BM, BN, WM, WN, 6>(af, lda, wf, cf, ldc, m, n, k, epi, stream, use_sk);
+      return pipe ? launch_glds_t<float, BM, BN, WM, WN, 3>(af, lda, wf, cf, ldc, m, n, k, epi, stream, use_sk)
+                  : launch_glds_t<float, BM, BN, WM, WN, NST2>(af, lda, wf, cf, ldc, m, n, k, epi, stream, use_sk);
+    }
   }
   if (dtype == DT_BF16)
     return launch_cfg_t<bf16_t, BM, BN, WM, WN>(static_cast<const bf16_t*>(a), lda, static_cast<const bf16_t*>(w),
@@ -623,7 +749,8 @@ constexpr TileCfg kTiles[] = {{C128x128, 128, 128}, {C128x64, 128, 64}, {C64x64,
 
 // does launch_cfg() send this config to the LDS-DMA ring kernel?
 bool takes_ring(const TileCfg& t, long long tiles, int dtype) {
-  return (t.id == C128x128 || t.id == C128x64 || t.id == C64x64) && (t.bm + t.bn < 256 || tiles <= 256) &&
+  return (t.id == C128x128 || t.id == C128x64 || t.id == C64x64) &&
+         (casync_opts().gemm_pipe != 0 || t.bm + t.bn < 256 || tiles <= 256) &&
          ((dtype == DT_BF16 && glds_mode() >= 1) || (dtype == DT_F32 && glds_mode() >= 2));
 }
 
@@ -692,7 +819,7 @@ const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype, b
   const long long tiles = (long long)((m + tc.bm - 1) / tc.bm) * (n / tc.bn);
   if (takes_ring(tc, tiles, dtype))
     snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, %d, false>", t, cfg,
-             tc.bm + tc.bn >= 256 ? 3 : 2);
+             casync_opts().gemm_pipe != 0 || tc.bm + tc.bn >= 256 ? 3 : 2);
   else
     snprintf(buf, sizeof(buf), "pw_gemm_kernel<%s, %s>", t, cfg);
   return buf;
@@ -736,9 +863,12 @@ int launch_conv_t(const T* in, const T* w, T* out, int ldc, int m, int n, int k,
   bool sk = false;
   const int cfg = pick_cfg(m, n, k, epi.sk_ws != nullptr, dtype, &sk, epi.concurrent != 0);
   // the ring kernel's two 48-KB-class tiles; the A "leading dimension" is unused (rows are gathered)
+  const bool pipe = casync_opts().gemm_pipe != 0;
   if (cfg == C64x64 || n % 64 || m <= 4096)
-    return launch_glds_t<T, 64, 64, 2, 2, 2, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C64x64);
-  return launch_glds_t<T, 128, 64, 2, 2, 2, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C128x64);
+    return pipe ? launch_glds_t<T, 64, 64, 2, 2, 3, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C64x64)
+                : launch_glds_t<T, 64, 64, 2, 2, 2, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C64x64);
+  return pipe ? launch_glds_t<T, 128, 64, 2, 2, 3, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C128x64)
+              : launch_glds_t<T, 128, 64, 2, 2, 2, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C128x64);
 }
 }  // namespace
 
@@ -749,8 +879,8 @@ const char* conv3x3_gemm_kernel_name(int batch, int h, int wdt, int cin, int cou
   const int m = batch * ho * wo;
   const int cfg = pick_cfg(m, cout, 9 * cin, stream_k, dtype, nullptr, concurrent);   // the launch's own choice
   const bool small = cfg == C64x64 || cout % 64 || m <= 4096;
-  snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, 2, 2, 2, true>", dtype == DT_BF16 ? "__bf16" : "float",
-           small ? "64, 64" : "128, 64");
+  snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, 2, 2, %d, true>", dtype == DT_BF16 ? "__bf16" : "float",
+           small ? "64, 64" : "128, 64", casync_opts().gemm_pipe != 0 ? 3 : 2);
   return buf;
 }
 

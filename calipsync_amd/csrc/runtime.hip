@@ -21,6 +21,7 @@ const OptField kFields[] = {
     {"gemm_streamk", &CasyncOptions::gemm_streamk},
     {"gemm_glds", &CasyncOptions::gemm_glds},
     {"gemm_cfg", &CasyncOptions::gemm_cfg},
+    {"gemm_pipe", &CasyncOptions::gemm_pipe},
     {"gemm_persist", &CasyncOptions::gemm_persist},
     {"gemm_conc", &CasyncOptions::gemm_conc},
     {"gemm_conc_tiles", &CasyncOptions::gemm_conc_tiles},
@@ -32,6 +33,7 @@ const OptField kFields[] = {
     {"dw_lds_bytes", &CasyncOptions::dw_lds_bytes},
     {"conv_im2col", &CasyncOptions::conv_im2col},
     {"att_nz", &CasyncOptions::att_nz},
+    {"dbg_noload", &CasyncOptions::dbg_noload},
 };
 
 thread_local const CasyncOptions* t_current = nullptr;

@@ -51,3 +51,138 @@ def predictions_to_uint8(pred: torch.Tensor) -> torch.Tensor:
             _lib.check(_lib.load().casync_op_pred_to_u8(pred.data_ptr(), out.data_ptr(), b, _stream(pred.device)),
                        "pred_to_u8")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# process_batch on the device (reference infer_api.py:192-357)
+# ---------------------------------------------------------------------------------------------------------------
+import numpy as np  # noqa: E402
+
+GEOM_WORDS = 12
+
+
+def audio_windows_host(features: np.ndarray, indices) -> np.ndarray:
+    """``FrameSynthesizer._get_audio_features`` (infer_api.py:99-145) on the host: [len(indices),32,32,32] fp32.
+    Same rule as ``audio_window_gather_kernel`` (closed form of the reference's truncated zero pads: a window
+    is ``pl`` zero rows + features[start:start+n0] + zero rows, or all zeros when that is not 16 rows)."""
+    n = features.shape[0]
+    out = np.zeros((len(indices), 16, 2, 1024), dtype=np.float32)
+    for k, idx in enumerate(indices):
+        left0, right0 = idx - 8, idx + 8
+        pad_left, pad_right = max(0, -left0), max(0, right0 - n)
+        left, right = max(left0, 0), min(right0, n)
+        start = min(left, n)
+        stop = min(right if right >= 0 else max(n + right, 0), n)
+        n0 = max(0, stop - start)
+        pl = min(pad_left, n0)
+        pr = min(pad_right, n0 + pl)
+        if n0 + pl + pr == 16:
+            out[k, pl:pl + n0] = features[start:start + n0]
+    return out.reshape(len(indices), 32, 32, 32)
+
+
+def crop_box(lms, height: int, img_width: int):
+    """The crop box of infer_api.py:206-231: (ymin, ymax, xmin, xmax, width); `width` is xmax - xmin BEFORE the
+    border clamps (it is the size the synthesised crop is resized to, :277)."""
+    xmin, ymin, xmax = int(lms[1][0]), int(lms[52][1]), int(lms[31][0])
+    width = xmax - xmin
+    ymax = ymin + width
+    if ymax > height:
+        diff = ymax - height
+        ymax = height
+        ymin = max(0, ymin - diff)
+    if ymin < 0:
+        ymax = min(height, ymax - ymin)
+        ymin = 0
+    xmin = max(xmin, 0)
+    xmax = min(xmax, img_width)
+    return ymin, ymax, xmin, xmax, width
+
+
+def process_batch_device(net, batch_images, batch_landmarks, batch_masks, *, windows=None, features=None,
+                         frame_indices=None):
+    """``FrameSynthesizer.process_batch`` with everything between the crop box and the pasted-back frame on the
+    GPU: ONE upload (the crop regions of all frames, concatenated), cv2.resize -> model input -> ``net`` ->
+    uint8 -> resize back -> polygon mask -> dilate -> blend, ONE download (the blended regions).
+
+    ``windows``: device tensor [B,32,32,32] (host-built HuBERT windows, the reference's own calling form), or
+    ``features`` [T,2,1024] on the device + ``frame_indices`` (windows gathered on the device).
+    Returns the list of synthesised frames (copies; the inputs are not modified, like infer_api.py:201)."""
+    lib = _lib.load()
+    dev = net._device()
+    if dev.type != "cuda":
+        raise RuntimeError("process_batch_device needs the model on a ROCm device (no CPU fallback)")
+    B = len(batch_images)
+    if B == 0:
+        return []
+    geom = np.zeros((B, GEOM_WORDS), dtype=np.int32)
+    pts = np.zeros((B, 33, 2), dtype=np.int32)
+    boxes, regions, fmasks = [], [], []
+    reg_off = synth_off = mask_off = fmask_off = 0
+    for i, (img, lms, mask) in enumerate(zip(batch_images, batch_landmarks, batch_masks)):
+        if img is None or img.ndim != 3 or img.shape[2] != 3 or img.dtype != np.uint8:
+            raise ValueError(f"frame {i}: expected a uint8 HxWx3 image")
+        ymin, ymax, xmin, xmax, width = crop_box(lms, img.shape[0], img.shape[1])
+        h, w = ymax - ymin, xmax - xmin
+        if h <= 0 or w <= 0 or width <= 0:
+            raise ValueError(f"frame {i}: empty crop box {(ymin, ymax, xmin, xmax)} (cv2.resize would fail)")
+        boxes.append((ymin, ymax, xmin, xmax, width))
+        regions.append(np.ascontiguousarray(img[ymin:ymax, xmin:xmax]).reshape(-1))
+        fp = np.asarray(lms[:33], dtype=np.float64).copy()          # infer_api.py:281-289
+        fp[:, 0] -= xmin
+        fp[:, 1] -= ymin
+        fp[:, 0] *= width / (xmax - xmin)
+        fp[:, 1] *= width / (ymax - ymin)
+        pts[i] = fp.astype(np.int32)
+        valid = int(width == h and width == w)
+        g = geom[i]
+        g[0], g[1], g[2], g[3], g[4], g[5], g[6] = reg_off, h, w, width, valid, synth_off, mask_off
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.float32)
+            g[7], g[8], g[9] = fmask_off, m.shape[0], m.shape[1]
+            fmasks.append(m.reshape(-1))
+            fmask_off += m.size
+        else:
+            g[7] = -1
+        reg_off += h * w * 3
+        mask_off += h * w
+        if valid:
+            synth_off += width * width * 3
+        if reg_off >= 2 ** 31:
+            raise ValueError("batch too large for 32-bit region offsets")
+    max_h, max_w = int(geom[:, 1].max()), int(geom[:, 2].max())
+    max_width = int((geom[:, 3] * geom[:, 4]).max())
+    stream = _stream(dev)
+    with torch.cuda.device(dev):
+        up = lambda a: torch.from_numpy(a).to(dev, non_blocking=False)
+        regions_dev = up(np.concatenate(regions))
+        geom_dev, pts_dev = up(geom.reshape(-1)), up(pts.reshape(-1))
+        fmasks_dev = up(np.concatenate(fmasks)) if fmasks else None
+        crops = torch.empty((B, 168, 168, 3), dtype=torch.uint8, device=dev)
+        x = torch.empty((B, 6, 160, 160), dtype=torch.float32, device=dev)
+        _lib.check(lib.casync_frame_prepare(regions_dev.data_ptr(), geom_dev.data_ptr(), B, crops.data_ptr(), x.data_ptr(),
+                                            stream), "casync_frame_prepare")
+        if windows is not None:
+            pred = net(x, windows)
+        else:
+            pred = net.forward_windows(x, features, frame_indices)
+        synth = torch.empty(max(synth_off, 16), dtype=torch.uint8, device=dev)
+        mask_a = torch.empty(mask_off, dtype=torch.uint8, device=dev)
+        mask_b = torch.empty(mask_off, dtype=torch.uint8, device=dev)
+        area = torch.empty(B, dtype=torch.int32, device=dev)
+        out_regions = torch.empty(reg_off, dtype=torch.uint8, device=dev)
+        _lib.check(lib.casync_frame_paste_back(
+            regions_dev.data_ptr(), geom_dev.data_ptr(), pts_dev.data_ptr(),
+            fmasks_dev.data_ptr() if fmasks_dev is not None else 0, crops.data_ptr(), pred.data_ptr(), B, max_h, max_w,
+            max_width, mask_off, synth.data_ptr(), mask_a.data_ptr(), mask_b.data_ptr(), area.data_ptr(),
+            out_regions.data_ptr(), stream), "casync_frame_paste_back")
+        host = out_regions.cpu().numpy()                    # the ONE download of the batch
+    results = []
+    for i, img in enumerate(batch_images):
+        out = img.copy()
+        if geom[i, 4]:
+            ymin, ymax, xmin, xmax, _ = boxes[i]
+            h, w = ymax - ymin, xmax - xmin
+            out[ymin:ymax, xmin:xmax] = host[geom[i, 0]:geom[i, 0] + h * w * 3].reshape(h, w, 3)
+        results.append(out)
+    return results

@@ -1,0 +1,267 @@
+"""Drop-in host side of the reference frame loop on the MI355X engine.
+
+``FrameSynthesizer`` keeps the reference's constructor, attributes and methods
+(image_infer_v1/tools/frame_synthesizer/infer_api.py:12-455):
+
+    FrameSynthesizer(unet_checkpoint, data_dir, device="cuda:0", batch_size=8)
+    .iterate_synthesized_frames(features, start_frame_idx=0, is_generate_sync_frame=True)
+        -> iterator of {'frame', 'index', 'physical_index'}
+    .process_batch(batch_images, batch_landmarks, batch_masks, hubert_features) -> list of uint8 frames
+
+What changes underneath: the model is ``calipsync_amd.unet.Model`` (HIP engine), and ``process_batch``
+runs crop + resize + model + paste-back blend on the GPU (``calipsync_amd.frame_loop``) with one upload
+and ONE download per batch instead of per-frame cv2 calls and B separate ``.cpu()`` copies
+(infer_api.py:200-253, 263-346).  Inside ``iterate_synthesized_frames`` the clip's HuBERT array is
+uploaded once and the 16-step windows are gathered on the device (``Model.forward_windows``) instead
+of being materialised on the host per batch (infer_api.py:99-145, 257).
+
+Frame sequencing (the ping-pong "motion generalisation" walk, infer_api.py:147-190) is restated
+statement by statement; the only addition is an optional ``seed`` so a run can be reproduced (the
+reference draws from the unseeded module-level ``random``).  File I/O (``cv2.imread`` /
+``np.loadtxt``, infer_api.py:52-97) stays host code behind the same methods; where cv2 is not
+installed JPEGs are decoded with Pillow (same libjpeg, BGR order restored).
+"""
+from __future__ import annotations
+
+import os
+import random
+import time
+from concurrent.futures import ThreadPoolExecutor
+from typing import Dict, Iterator, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import frame_loop
+from .unet import Model
+
+
+def _imread(path: str, gray: bool = False) -> Optional[np.ndarray]:
+    """cv2.imread replacement: BGR uint8 HxWx3 (or HxW for gray); None when the file cannot be read."""
+    try:
+        import cv2  # noqa: WPS433  (optional: the reference's own decoder when it is installed)
+        return cv2.imread(path, cv2.IMREAD_GRAYSCALE if gray else cv2.IMREAD_COLOR)
+    except ImportError:
+        pass
+    if path.endswith(".npy"):
+        return np.load(path)
+    try:
+        from PIL import Image
+        with Image.open(path) as im:
+            if gray:
+                return np.asarray(im.convert("L"))
+            return np.ascontiguousarray(np.asarray(im.convert("RGB"))[:, :, ::-1])
+    except Exception:
+        return None
+
+
+class FrameSynthesizer:
+    def __init__(self, unet_checkpoint: Optional[str], data_dir: str, device: str = "cuda:0", batch_size: int = 8, *,
+                 seed: Optional[int] = None, precision: str = "fp32", net: Optional[Model] = None):
+        """Same positional arguments as the reference (infer_api.py:13-14).  Keyword-only extensions:
+        ``seed`` (reproducible frame walk), ``precision`` (engine storage type), ``net`` (an already
+        loaded ``Model`` instead of a checkpoint path)."""
+        self.device = device
+        self.data_dir = data_dir
+        self.batch_size = batch_size
+        self.frames_dir = os.path.join(data_dir, "frames")
+        self.positions_dir = os.path.join(data_dir, "positions")
+        self.masks_dir = os.path.join(data_dir, "masks")
+        # infer_api.py:34 counts the .jpg frames; .npy frames are accepted too (synthetic data sets)
+        names = os.listdir(self.frames_dir)
+        self._ext = ".jpg" if any(f.endswith(".jpg") for f in names) else ".npy"
+        self.total_frames = len([f for f in names if f.endswith(self._ext)])
+        self.executor = ThreadPoolExecutor(max_workers=self.batch_size)   # infer_api.py:38
+        if net is None:                                                   # infer_api.py:41-43
+            net = Model(6, "hubert", precision=precision).to(device)
+            net.load_state_dict(torch.load(unet_checkpoint, map_location="cpu"))
+        self.net = net.eval()
+        # frame-walk state (infer_api.py:46-50)
+        self.current_direction = None
+        self.target_frame_count = 0
+        self.processed_frame_count = 0
+        self.current_frame_position = 0
+        self.last_logical_index = -1
+        self._rng = random.Random(seed) if seed is not None else random   # reference: module-level random
+        self._features_dev = None        # (id of the host array, device copy) of the clip being synthesised
+
+    # ------------------------------------------------------------------ file I/O (infer_api.py:52-97)
+    def _load_single_frame(self, frame_idx: int) -> tuple:
+        frame_number = str(frame_idx % self.total_frames).zfill(6)
+        img = _imread(os.path.join(self.frames_dir, f"{frame_number}{self._ext}"))
+        lms = np.loadtxt(os.path.join(self.positions_dir, f"{frame_number}.txt"))
+        mask = None
+        for ext in (".jpg", ".npy"):
+            mask_path = os.path.join(self.masks_dir, f"{frame_number}{ext}")
+            if os.path.exists(mask_path):
+                mask = _imread(mask_path, gray=True)
+                if mask is not None:
+                    mask = mask.astype(np.float32) / 255.0
+                break
+        return img, lms, mask
+
+    def _load_batch_frames(self, frame_indices: list) -> tuple:
+        futures = [self.executor.submit(self._load_single_frame, i) for i in frame_indices]
+        batch_images, batch_landmarks, batch_masks = [], [], []
+        for future in futures:
+            img, lms, mask = future.result()
+            batch_images.append(img)
+            batch_landmarks.append(lms)
+            batch_masks.append(mask)
+        return batch_images, batch_landmarks, batch_masks
+
+    # ------------------------------------------------------------------ audio windows (infer_api.py:99-145)
+    def _get_audio_features(self, features: np.ndarray, indices: list) -> np.ndarray:
+        """Host-side windows [len(indices), 32, 32, 32] with the reference's exact rule (truncated
+        ``zeros_like`` pads, all-zero default window when the padded slice misses 16 rows).  The device
+        path does not call this (``Model.forward_windows`` gathers on the GPU); it exists for callers of
+        ``process_batch`` that hold host windows, as the reference's own loop does."""
+        return frame_loop.audio_windows_host(features, indices)
+
+    # ------------------------------------------------------------------ frame walk (infer_api.py:147-190)
+    def _generate_frame_sequence(self, needed_frames: int) -> list:
+        frame_sequence = []
+        # re-draw direction and run length when the current run is used up (5-15 % of the clip)
+        if self.processed_frame_count >= self.target_frame_count or self.current_direction is None:
+            self.target_frame_count = self.total_frames * self._rng.randint(5, 15) // 100
+            self.current_direction = self._rng.choice([1, -1])
+            self.processed_frame_count = 0
+        while len(frame_sequence) < needed_frames:
+            if self.current_direction == 1:
+                available_frames = self.total_frames - self.current_frame_position
+            else:
+                available_frames = self.current_frame_position + 1
+            seq_length = min(available_frames, needed_frames - len(frame_sequence))
+            for _ in range(seq_length):
+                frame_sequence.append(self.current_frame_position)
+                self.current_frame_position += self.current_direction
+                if self.current_frame_position >= self.total_frames:      # bounce at the end
+                    self.current_frame_position = self.total_frames - 2
+                    self.current_direction = -1
+                elif self.current_frame_position < 0:                     # bounce at the start
+                    self.current_frame_position = 1
+                    self.current_direction = 1
+        self.processed_frame_count += len(frame_sequence)
+        return frame_sequence
+
+    # ------------------------------------------------------------------ the batch (infer_api.py:192-357)
+    def process_batch(self, batch_images: list, batch_landmarks: list, batch_masks: list,
+                      hubert_features: np.ndarray) -> list:
+        """Reference signature.  ``hubert_features``: host windows [B,32,32,32].  Like the reference,
+        any failure returns the un-synced originals (infer_api.py:352-357) -- after printing it."""
+        try:
+            windows = torch.from_numpy(np.ascontiguousarray(hubert_features, dtype=np.float32)).to(self.device)
+            return frame_loop.process_batch_device(self.net, batch_images, batch_landmarks, batch_masks, windows=windows)
+        except Exception as exc:   # the reference swallows everything here; keep the contract, say why
+            print(f"process_batch failed, returning the original frames: {exc!r}")
+            return batch_images
+
+    def _process_batch_indices(self, batch_images, batch_landmarks, batch_masks, features_dev, indices) -> list:
+        try:
+            return frame_loop.process_batch_device(self.net, batch_images, batch_landmarks, batch_masks,
+                                                   features=features_dev, frame_indices=indices)
+        except Exception as exc:
+            print(f"process_batch failed, returning the original frames: {exc!r}")
+            return batch_images
+
+    # ------------------------------------------------------------------ the loop (infer_api.py:359-451)
+    def iterate_synthesized_frames(self, features: np.ndarray, start_frame_idx: int = 0,
+                                   is_generate_sync_frame: bool = True) -> Iterator[Dict]:
+        self.last_logical_index = start_frame_idx - 1
+        time_stats = {"load_frame": 0.0, "get_audio": 0.0, "process_batch": 0.0}
+        total_frames = len(features)
+        features_dev = None
+        try:
+            if is_generate_sync_frame and total_frames:
+                t0 = time.time()   # one upload of the whole [T,2,1024] array replaces B x 128 KB per batch
+                features_dev = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).to(self.device)
+                time_stats["get_audio"] += time.time() - t0
+            for batch_start in range(0, total_frames, self.batch_size):
+                try:
+                    batch_end = min(batch_start + self.batch_size, total_frames)    # variable last batch
+                    frame_sequence = self._generate_frame_sequence(batch_end - batch_start)
+                    t0 = time.time()
+                    batch_images, batch_landmarks, batch_masks = self._load_batch_frames(frame_sequence)
+                    time_stats["load_frame"] += time.time() - t0
+                    if not is_generate_sync_frame:
+                        for i, original_image in enumerate(batch_images):
+                            self.last_logical_index += 1
+                            yield {"frame": original_image, "index": self.last_logical_index,
+                                   "physical_index": frame_sequence[i]}
+                        continue
+                    t0 = time.time()
+                    processed = self._process_batch_indices(batch_images, batch_landmarks, batch_masks, features_dev,
+                                                            list(range(batch_start, batch_end)))
+                    time_stats["process_batch"] += time.time() - t0
+                    for i, frame in enumerate(processed):
+                        self.last_logical_index += 1
+                        yield {"frame": frame, "index": self.last_logical_index, "physical_index": frame_sequence[i]}
+                except Exception as exc:        # a failed batch is skipped, the iterator goes on (:429-436)
+                    print(f"batch starting at {batch_start} failed: {exc!r}")
+                    time.sleep(0.1)
+                    continue
+        except Exception as exc:                # fatal: one black frame so the consumer does not hang (:438-446)
+            print(f"frame iterator failed: {exc!r}")
+            self.last_logical_index += 1
+            yield {"frame": np.zeros((480, 640, 3), dtype=np.uint8), "index": self.last_logical_index,
+                   "physical_index": 0}
+        finally:
+            total_time = sum(time_stats.values())
+            if total_time > 0:
+                print(f"average frame rate: {total_frames / total_time:.2f} FPS "
+                      f"(load {time_stats['load_frame']:.2f} s, audio {time_stats['get_audio']:.2f} s, "
+                      f"batches {time_stats['process_batch']:.2f} s)")
+
+    def __del__(self):
+        if hasattr(self, "executor"):
+            self.executor.shutdown()
+
+
+class VideoStreamManager:
+    """Offline driver with the reference's signature (inference.py:14-20, 47): features -> frames -> file.
+
+    HuBERT extraction is outside the hot-path contract (the north star consumes
+    pre-extracted windows; no HuBERT weights ship), so ``hubert_path`` may be a callable
+    ``audio_path -> [T,2,1024] array`` or is ignored when ``audio_path`` is itself a ``.npy`` of
+    features.  The mp4 writer / ffmpeg mux (inference.py:88-110) is used when cv2 / ffmpeg exist; otherwise
+    the frames go to ``<output_path>.npy``."""
+
+    def __init__(self, data_dir: str, unet_checkpoint: Optional[str], hubert_path=None, device: str = "cuda:0",
+                 batch_size: int = 8, output_sample_rate: int = 24000, **synth_kwargs):
+        self.synthesizer = FrameSynthesizer(unet_checkpoint=unet_checkpoint, data_dir=data_dir, device=device,
+                                            batch_size=batch_size, **synth_kwargs)
+        self.hubert_extractor = hubert_path if callable(hubert_path) else None
+        self.feature_sample_rate = 16000
+        self.output_sample_rate = output_sample_rate
+        self.fps = 25
+
+    def process_single_file(self, audio_path: str, output_path: str):
+        if audio_path.endswith(".npy"):
+            features = np.load(audio_path)
+        elif self.hubert_extractor is not None:
+            features = self.hubert_extractor(audio_path)
+        else:
+            raise RuntimeError("no HuBERT extractor configured: pass pre-extracted features (.npy) or a callable")
+        frames = [info["frame"] for info in self.synthesizer.iterate_synthesized_frames(features, 0, True)]
+        if not frames:
+            raise ValueError("no video frame was generated")
+        try:
+            import cv2
+        except ImportError:
+            np.save(output_path + ".npy", np.stack(frames))
+            return output_path + ".npy"
+        height, width = frames[0].shape[:2]
+        temp = output_path.replace(".mp4", "_temp.mp4")
+        writer = cv2.VideoWriter(temp, cv2.VideoWriter_fourcc(*"mp4v"), self.fps, (width, height))
+        for frame in frames:
+            writer.write(frame)
+        writer.release()
+        import shutil
+        import subprocess
+        if shutil.which("ffmpeg") and not audio_path.endswith(".npy"):
+            subprocess.run(["ffmpeg", "-y", "-i", temp, "-i", audio_path, "-c:v", "copy", "-c:a", "aac", "-strict",
+                            "experimental", "-map", "0:v:0", "-map", "1:a:0", output_path], capture_output=True)
+            os.remove(temp)
+        else:
+            os.replace(temp, output_path)
+        return output_path

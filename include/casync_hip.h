@@ -145,6 +145,9 @@ int casync_op_pw_gemm(const void* a, int lda, const void* w, const float* bias,
                       const void* pre_res, int ld_pre, const float* pre_scale,
                       const void* post_res, int ld_post,
                       const float* aff_s, const float* aff_t, casync_stream stream);
+/* Diagnostic (tools/experiments/gemm_timeline.py): the casync_op_pw_gemm calls this thread makes next
+ * write 8 timestamp words per workgroup into dev_words (NULL = off).  Never used by the engine.  */
+int casync_debug_gemm_stamps(void* dev_words);
 /* nn.Conv2d(k=3, bias) + folded BN + LeakyReLU of the audio encoder (conv3: stride 2 pad 1, conv5: stride 2
  * pad 3; module/unet.py:161-168) as an implicit GEMM: in [B,H,W,cin] NHWC, w [cout][(ky,kx,cin)],
  * out [B,Ho,Wo,cout].  cin % (128 B / elem) == 0, cout % 64 == 0. */
@@ -193,6 +196,30 @@ int casync_op_cross_attention(const void* q, int ldq, const void* k, int ldk,
  *   (truncation) -- infer_api.py:265-266.  Bit-exact; cv2.resize / blending stay on the host. */
 int casync_op_crop_to_input(const uint8_t* crops168_dev, float* x_dev, int batch, casync_stream stream);
 int casync_op_pred_to_u8(const float* pred_dev, uint8_t* out_dev, int batch, casync_stream stream);
+/* The image arithmetic of FrameSynthesizer.process_batch on ragged per-frame regions (infer_api.py:234-235 and
+ * 263-346).  The host slices every frame's crop box img[ymin:ymax, xmin:xmax] (infer_api.py:206-234) into ONE
+ * byte buffer `regions` (h x w x 3 uint8 each, contiguous) and describes frame b in geom[b*12 .. b*12+11]
+ * (int32): { region byte offset, h, w, width (xmax-xmin BEFORE the clamps: side of the synthesised square),
+ * valid (1 when (width,width) == (h,w), else the frame is returned unchanged: infer_api.py:320-324), byte offset in
+ * `synth`, byte offset in the two mask buffers, float offset of the optional frame mask in `fmasks` (-1 = none), its
+ * height, its width, 0, 0 }.  pts: [B][33][2] int32 = the contour points already shifted / scaled / truncated
+ * (infer_api.py:281-289).
+ *   casync_frame_prepare: cv2.resize(region, (168,168)) -> crops168 [B,168,168,3] u8, and (x_dev != NULL) the
+ *     [B,6,160,160] model input of casync_op_crop_to_input.
+ *   casync_frame_paste_back: crop[4:164,4:164] = uint8(pred*255); cv2.resize to (width,width); cv2.fillPoly; area-
+ *     scaled cv2.dilate; float64 blend with the original region (and the optional float mask, resized) -> out_regions
+ *     (same layout as `regions`).  synth / mask_a / mask_b / area are scratch (sizes: sum of width*width*3, 2 x
+ *     mask_bytes = sum of h*w, B int32).
+ * OpenCV's arithmetic is restated from its published sources (resize.cpp, drawing.cpp, morph.cpp); cv2 is not
+ * available in the build image, so parity with the real library is UNPINNED; parity with the CPU restatement
+ * (oracle/frame_ops_oracle.py) is bit-exact.                                                                    */
+int casync_frame_prepare(const uint8_t* regions_dev, const int32_t* geom_dev, int batch, uint8_t* crops168_dev,
+                         float* x_dev, casync_stream stream);
+int casync_frame_paste_back(const uint8_t* regions_dev, const int32_t* geom_dev, const int32_t* pts_dev,
+                            const float* fmasks_dev, const uint8_t* crops168_dev, const float* pred_dev, int batch,
+                            int max_h, int max_w, int max_width, int64_t mask_bytes, uint8_t* synth_dev,
+                            uint8_t* mask_a_dev, uint8_t* mask_b_dev, int32_t* area_dev, uint8_t* out_regions_dev,
+                            casync_stream stream);
 /* NCHW <-> NHWC helpers */
 int casync_op_nchw_to_nhwc(const float* in, void* out, int batch, int c, int hw,
                            casync_stream stream);

@@ -80,3 +80,41 @@ def crops_to_model_input(crops168: np.ndarray) -> np.ndarray:
 def predictions_to_uint8(pred: np.ndarray) -> np.ndarray:
     """[B,3,160,160] fp32 -> [B,160,160,3] uint8 (infer_api.py:265-266)."""
     return np.stack([np.array(p.transpose(1, 2, 0) * 255, dtype=np.uint8) for p in pred])
+
+
+class FrameWalk:
+    """Literal restatement of the frame-walk state machine of ``FrameSynthesizer._generate_frame_sequence``
+    (infer_api.py:45-50, 147-190) with an injectable ``random``-like source -- the checker of
+    ``calipsync_amd.frame_synth.FrameSynthesizer._generate_frame_sequence``."""
+
+    def __init__(self, total_frames: int, rng):
+        self.total_frames = total_frames
+        self.rng = rng
+        self.current_direction = None
+        self.target_frame_count = 0
+        self.processed_frame_count = 0
+        self.current_frame_position = 0
+
+    def generate(self, needed_frames: int) -> list:
+        frame_sequence = []
+        if self.processed_frame_count >= self.target_frame_count or self.current_direction is None:
+            self.target_frame_count = self.total_frames * self.rng.randint(5, 15) // 100     # :160
+            self.current_direction = self.rng.choice([1, -1])                                # :161
+            self.processed_frame_count = 0
+        while len(frame_sequence) < needed_frames:                                           # :165
+            if self.current_direction == 1:
+                available_frames = self.total_frames - self.current_frame_position
+            else:
+                available_frames = self.current_frame_position + 1
+            seq_length = min(available_frames, needed_frames - len(frame_sequence))
+            for _ in range(seq_length):
+                frame_sequence.append(self.current_frame_position)
+                self.current_frame_position += self.current_direction
+                if self.current_frame_position >= self.total_frames:                         # :180-182
+                    self.current_frame_position = self.total_frames - 2
+                    self.current_direction = -1
+                elif self.current_frame_position < 0:                                        # :183-185
+                    self.current_frame_position = 1
+                    self.current_direction = 1
+        self.processed_frame_count += len(frame_sequence)                                    # :188
+        return frame_sequence
