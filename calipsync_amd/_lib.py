@@ -48,6 +48,7 @@ _PROTOS = {
                                          c_i64, C.c_void_p, C.POINTER(KernelTime), C.c_int]),
     "casync_op_set_dtype": (C.c_int, [C.c_int]),
     "casync_debug_gemm_stamps": (C.c_int, [C.c_void_p]),
+    "casync_debug_ir_stamps": (C.c_int, [C.c_void_p]),
     "casync_op_pw_gemm": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_f32p, c_f32p,
                                     C.c_int, c_f32p, c_f32p, C.c_void_p]),

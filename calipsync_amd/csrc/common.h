@@ -47,23 +47,24 @@ struct CasyncOptions {
   int lanes = 2;             // CASYNC_LANES: concurrent sub-batch lanes (1..4) from 2*16 frames up
   int trunk_lanes = 0;       // CASYNC_TRUNK_LANES: lanes of the 10x10 trunk (0 = same as `lanes`; 1 = the
                              //   lanes join before the fusion MLP and the trunk runs as one stream-K lane)
+  int lane_skew = 0;         // CASYNC_LANE_SKEW: two lanes of batch/2 + skew and batch/2 - skew frames (experiment)
   int overlap = 1;           // CASYNC_OVERLAP: audio encoder on its own stream per lane
   int gemm_streamk = 1;      // CASYNC_GEMM_STREAMK: stream-K remainders in single-lane runs
   int gemm_glds = 2;         // CASYNC_GEMM_GLDS: LDS-DMA ring GEMM: 0 off, 1 bf16 only, 2 both types
   int gemm_cfg = -1;         // CASYNC_GEMM_CFG: force one tile configuration
-  int gemm_pipe = 3;         // CASYNC_GEMM_PIPE: stages of the software-pipelined LDS-DMA ring, 3..6 (0 = the round-1 loop)
+  int gemm_pipe = 0;         // CASYNC_GEMM_PIPE: stages of the software-pipelined LDS-DMA ring, 3..6 (0 = the round-1 loop)
   int gemm_persist = 1;      // CASYNC_GEMM_PERSIST: persistent grid of the register-staged GEMM
   int gemm_conc = 3;         // CASYNC_GEMM_CONC: tile policy when lanes share the chip
   int gemm_conc_tiles = 2048;  // CASYNC_GEMM_CONC_TILES
   int fuse_ir = 1;           // CASYNC_FUSE_IR: fused inverted-residual kernel
   int fuse_up = 1;           // CASYNC_FUSE_UP: bilinear upsample folded into up3/up4
   int fuse_min_hw = 32;      // CASYNC_FUSE_MIN_HW: lowest resolution the fused kernel is used at
+  int ir_ws = 0;             // CASYNC_IR_WS: wave-specialised fused inverted residual (fp32): MFMA waves + depthwise waves
   int fuse_q = 1;            // CASYNC_FUSE_Q: query projection as 64 extra columns of the p_1 GEMM
   int dw_lds = 1;            // CASYNC_DW_LDS: LDS-slab depthwise kernel
   int dw_lds_bytes = 32768;  // CASYNC_DW_LDS_BYTES
   int conv_im2col = 0;       // CASYNC_CONV_IM2COL: dense 3x3 via im2col + GEMM instead of the implicit GEMM
   int att_nz = 0;            // CASYNC_ATT_NZ: channel split of the attention kernel (0 = by batch)
-  int dbg_noload = 0;        // CASYNC_DBG_NOLOAD: diagnostic (casync_op_pw_gemm only): no LDS-DMA after the ring is first filled
 };
 CasyncOptions& casync_default_options();      // process defaults (environment read once, thread-safe)
 const CasyncOptions& casync_opts();           // options of the call in progress on this thread
@@ -143,7 +144,7 @@ struct GemmEpilogue {
   float* sk_ws = nullptr;
   unsigned* sk_cnt = nullptr;
   unsigned long long* stamps = nullptr;   // diagnostic only: 8 words per workgroup (see pw_gemm_glds_kernel)
-  int dbg_noload = 0;                     // diagnostic only: skip the steady-state LDS-DMA (timing experiment)
+  unsigned buf_a_bytes = 0, buf_w_bytes = 0;   // extents of A and W for the buffer-addressed loads (set by the launcher)
   // the launch shares the chip with another lane's kernels (two-lane schedule): tile choice then
   // favours many small workgroups that interleave on a CU over few large ones (see pick_cfg)
   int concurrent = 0;

@@ -23,6 +23,10 @@ void casync_set_error(const char* fmt, ...) {
 }
 extern "C" const char* casync_last_error(void) { return g_err; }
 
+// diagnostic: device buffer of 8 x grid words that the GEMM launches of this thread stamp (null = off; see
+// casync_debug_gemm_stamps).  Never set on the product path.
+static thread_local unsigned long long* g_gemm_stamps = nullptr;
+
 namespace {
 
 // ------------------------------------------------------------------ architecture table
@@ -361,6 +365,7 @@ struct Plan {
       epi.sk_cnt = reinterpret_cast<unsigned*>(ctx + kStreamKFloats * 4);
     }
     epi.concurrent = concurrent ? 1 : 0;
+    epi.stamps = g_gemm_stamps;
     r.run(tag.c_str(), pw_gemm_kernel_name((int)m, n, k, epi.sk_ws != nullptr, dt(), concurrent),
           alg_flops > 0 ? alg_flops : 2.0 * m * n * k, bytes,
           [&] { return launch_pw_gemm(a, lda, w, c, ldc, (int)m, n, k, epi, r.s, dt()); });
@@ -835,6 +840,7 @@ static int run_forward(casync_handle h, const FwdArgs& A, hipStream_t caller, st
   int b0s[casync_engine::kMaxLanes], bls[casync_engine::kMaxLanes];
   for (int l = 0, b0 = 0; l < lanes; ++l) {
     bls[l] = A.batch / lanes + (l < A.batch % lanes ? 1 : 0);
+    if (lanes == 2 && o.lane_skew > 0 && o.lane_skew < A.batch / 2) bls[l] += l == 0 ? o.lane_skew : -o.lane_skew;
     b0s[l] = b0;
     b0 += bls[l];
   }
@@ -968,9 +974,6 @@ int64_t casync_tap(casync_handle h, const char* name, int batch, void* ws, void*
 }
 
 // ---- single operators ------------------------------------------------------
-// diagnostic: device buffer of 8 x grid words that the NEXT casync_op_pw_gemm calls of this thread stamp
-// (null = off).  Not part of the product path.
-static thread_local unsigned long long* g_gemm_stamps = nullptr;
 int casync_debug_gemm_stamps(void* dev_words) {
   g_gemm_stamps = static_cast<unsigned long long*>(dev_words);
   return CASYNC_OK;
@@ -1014,7 +1017,6 @@ int casync_op_pw_gemm(const void* a, int lda, const void* w, const float* bias, 
     e.sk_cnt = reinterpret_cast<unsigned*>(scratch[dev] + kStreamKFloats * 4);
   }
   e.stamps = g_gemm_stamps;
-  e.dbg_noload = casync_opts().dbg_noload;
   return launch_pw_gemm(a, lda, w, c, ldc, m, n, k, e, (hipStream_t)stream, g_op_dtype);
 }
 int casync_op_conv3x3(const void* in, const void* w, const float* bias, void* out, int batch, int h, int wdt,

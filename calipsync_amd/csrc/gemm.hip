@@ -295,6 +295,17 @@ inline StreamKSplit stream_k_split(long long tiles, int nk, int tile_floats, boo
 // refilled) -> issue tile kt+NST-1 -> MFMAs on tile kt.  One barrier per k-tile, loads stay in
 // flight across it.
 // =====================================================================================
+// 16 B per lane from a buffer straight into LDS: `buffer_load_dwordx4 v, s[rsrc], s_off offen lds`.  Per-lane byte
+// offset in a VGPR, a wave-uniform byte offset in an SGPR, LDS destination = wave-uniform base + lane * 16.  (The
+// descriptor type only exists in the device pass, hence the guard: the host pass sees an empty body.)
+__device__ __forceinline__ void buffer_load_lds16(const void* base, unsigned bytes, void __attribute__((address_space(3)))* lds,
+                                                  int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000), lds,
+                                           16, voff, soff, 0, 0);
+#endif
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // 256 B of zeros: where the implicit-GEMM convolution points its LDS-DMA loads for taps outside the image
@@ -388,7 +399,6 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
         tap = kg / kpt;
         tap_off = ((tap / 3) * epi.conv_w + tap % 3) * epi.conv_c + (kg - tap * kpt) * BK;
       }
-      if (epi.dbg_noload && kt >= NST) return;   // timing experiment only (wrong results): no LDS-DMA in the steady loop
 #pragma unroll
       for (int j = 0; j < LPT; ++j) {
         if (j < LPT * part / 4 || j >= LPT * (part + 1) / 4) continue;
@@ -426,7 +436,6 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
     }
     // one 32-B column pair (g) of the tile in stage `st`: the 16 B this lane feeds to four MFMA k-steps
     auto frag = [&](const char* st, int g, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
-      if (epi.dbg_noload >= 3) return;   // timing experiment without the LDS fragment reads
 #pragma unroll
       for (int i = 0; i < TM; ++i)
         fa[i] = *reinterpret_cast<const f32x4*>(st + a_off[i] + (((2 * g + kh) ^ a_key[i]) << 4));
@@ -457,7 +466,7 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
 #pragma unroll
       for (int t = 0; t < AHEAD; ++t)
         if (t < cnt) issue(t);
-      f32x4 fa0[TM] = {}, fb0[TN] = {}, fa1[TM] = {}, fb1[TN] = {};
+      f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
       // cold start: tile 0 (and tile 1) landed, the first column pair of tile 0 in registers
       if (cnt >= AHEAD) wait_vmcnt<(NST - 3) * LPT>(); else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
@@ -471,7 +480,7 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
         constexpr bool MORE = decltype(more_c)::value, NEXT = decltype(next_c)::value;
         // tiles <= kt+1 landed; FLIGHT later tiles (kt+2 ...) stay in flight
         wait_vmcnt<decltype(flight_c)::value * LPT>();
-        if (epi.dbg_noload < 2) __builtin_amdgcn_s_barrier();   // (>= 2: timing experiment without the barrier)
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const char* st = ring + (kt % NST) * STAGE;
         const char* st_next = ring + ((kt + 1) % NST) * STAGE;
@@ -516,6 +525,88 @@ __global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__
         else body(kt, std::false_type{}, std::true_type{}, integral_constant<int, 0>{});
       }
       body(kt, std::false_type{}, std::false_type{}, integral_constant<int, 0>{});
+    } else if constexpr (!CONV) {
+      // Two-stage loop with NO vector-ALU instruction in it.  On gfx950 an fp32 MFMA and a VALU instruction of ANY
+      // wave on the same SIMD do not overlap (tools/experiments/mfma_valu_overlap.hip: times add, ~5 cycles per
+      // wave-instruction), so the ~27 address instructions per k-tile of the plain loop (64-bit pointer bumps,
+      // readfirstlane for M0, LDS address adds) cost 13 % of a 64x64 tile's 1,024 MFMA cycles whatever the
+      // occupancy.  Here the loads are buffer_load ... lds: per-lane offset fixed for the whole tile, the k-tile
+      // offset in an SGPR, the LDS destination wave-uniform (SALU); the fragment addresses are per-lane constants
+      // and the stage offset is an instruction immediate (the loop is unrolled over the two stages).
+      const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+      int voff[LPT];
+#pragma unroll
+      for (int j = 0; j < LPT; ++j) {
+        const int r = (j * 4 + wave) * 8 + lrow8;
+        const int cs = lcol ^ ((r >> 1) & 7);
+        if (j < BM / 32) {
+          int row = m0 + r;
+          row = row < M ? row : M - 1;
+          voff[j] = (int)(((long long)row * lda) * (int)sizeof(T)) + cs * 16;
+        } else {
+          voff[j] = (int)(((long long)(n0 + r - BM) * K) * (int)sizeof(T)) + cs * 16;
+        }
+      }
+      auto issue2 = [&](int kt, int stage) {
+        const int soff = (k0 + kt) * ROWB;
+#pragma unroll
+        for (int j = 0; j < LPT; ++j)
+          buffer_load_lds16(j < BM / 32 ? static_cast<const void*>(A) : static_cast<const void*>(W),
+                            j < BM / 32 ? epi.buf_a_bytes : epi.buf_w_bytes,
+                            (void __attribute__((address_space(3)))*)(ring + stage * STAGE + (j * 4 + wave_s) * 8 * ROWB), voff[j], soff);
+      };
+      // per-lane fragment addresses of the four column pairs (stage 0); stage 1 = + STAGE, an immediate
+      const char* a_ptr[TM][4];
+      const char* b_ptr[TN][4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a_ptr[i][g] = ring + a_off[i] + (((2 * g + kh) ^ a_key[i]) << 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b_ptr[j][g] = ring + b_off[j] + (((2 * g + kh) ^ b_key[j]) << 4);
+      }
+      auto tile_mma = [&](auto stage_c) {
+        constexpr int SOFF = decltype(stage_c)::value * STAGE;
+        // the next column pair's fragments are read while the current pair's MFMAs run (two register sets)
+        f32x4 fa[2][TM], fb[2][TN];
+        auto rd = [&](int g, f32x4 (&xa)[TM], f32x4 (&xb)[TN]) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const f32x4*>(a_ptr[i][g] + SOFF);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) xb[j] = *reinterpret_cast<const f32x4*>(b_ptr[j][g] + SOFF);
+        };
+        rd(0, fa[0], fb[0]);
+        rd(1, fa[1], fb[1]);
+        mma(fa[0], fb[0]);
+        rd(2, fa[0], fb[0]);
+        mma(fa[1], fb[1]);
+        rd(3, fa[1], fb[1]);
+        mma(fa[0], fb[0]);
+        mma(fa[1], fb[1]);
+        // keep that order (the scheduler otherwise sinks every read next to its use)
+        constexpr int NM = TM * TN * (sizeof(T) == 4 ? 4 : 1), ND = TM + TN;
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * ND, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, NM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, NM, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, 2 * NM, 0);
+      };
+      issue2(0, 0);
+      for (int kt = 0; kt < cnt; kt += 2) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 1 < cnt) issue2(kt + 1, 1);
+        tile_mma(std::integral_constant<int, 0>{});
+        if (kt + 1 < cnt) {
+          wait_vmcnt<0>();
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          if (kt + 2 < cnt) issue2(kt + 2, 0);
+          tile_mma(std::integral_constant<int, 1>{});
+        }
+      }
     } else {
 #pragma unroll
       for (int s = 0; s < NST - 1; ++s)
@@ -664,8 +755,15 @@ int launch_glds_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, 
   const StreamKSplit sk = stream_k_split(nwg, k / (ROWB / (int)sizeof(T)), BM * BN, epi.sk_ws != nullptr && use_sk);
   const long long want = sk.dp_tiles + sk.wgs;
   const unsigned grid = (unsigned)(want > cap ? cap : want);
+  GemmEpilogue e2 = epi;
+  if constexpr (!CONV) {   // extents for the buffer-addressed loads of the two-stage loop (32-bit offsets)
+    const unsigned long long ab = ((unsigned long long)(m - 1) * lda + k) * sizeof(T), wb = (unsigned long long)n * k * sizeof(T);
+    CASYNC_REQUIRE(ab < (1ull << 31) && wb < (1ull << 31), "gemm: operand larger than 2 GiB");
+    e2.buf_a_bytes = (unsigned)ab;
+    e2.buf_w_bytes = (unsigned)wb;
+  }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a, lda, w, c, ldc, m, n, k, n_ntiles,
-                     (int)nwg, (int)sk.dp_tiles, sk.wgs, sk.per, epi);
+                     (int)nwg, (int)sk.dp_tiles, sk.wgs, sk.per, e2);
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }
@@ -697,6 +795,7 @@ inline int glds_mode() { return casync_opts().gemm_glds; }
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, int n, int k,
                const GemmEpilogue& epi, hipStream_t stream, int dtype, bool use_sk) {
+
   // ring depth: 128x128 -> 3 stages (96 KB, one workgroup per CU), 128x64 -> 2 stages (48 KB, three
   // per CU), 64x64 -> 2 stages (32 KB, five per CU).  Measured every time: one more co-resident
   // workgroup beats one more stage of prefetch (128x64: +1.5 % fp32, +3.6 % bf16 end to end;
@@ -707,7 +806,9 @@ int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, i
   // two co-resident workgroups.  The smaller tiles always take the ring.
   const long long tiles = (long long)((m + BM - 1) / BM) * (n / BN);
   const int pipe = casync_opts().gemm_pipe;   // software-pipelined ring: number of stages (0 = the round-1 loop)
-  const bool ring_ok = pipe != 0 || (BM + BN) < 256 || tiles <= 256;
+  const size_t esz = dtype == DT_BF16 ? 2 : 4;
+  const bool fits32 = ((size_t)(m - 1) * lda + k) * esz < (1ull << 31) && (size_t)n * k * esz < (1ull << 31);
+  const bool ring_ok = fits32 && (pipe != 0 || (BM + BN) < 256 || tiles <= 256);
   if constexpr (WM * WN == 4 && BN >= 64) {
     if (ring_ok && dtype == DT_BF16 && glds_mode() >= 1)
       return pipe ? launch_glds_t<bf16_t, BM, BN, WM, WN, 3>(static_cast<const bf16_t*>(a), lda,
@@ -880,7 +981,7 @@ const char* conv3x3_gemm_kernel_name(int batch, int h, int wdt, int cin, int cou
   const int cfg = pick_cfg(m, cout, 9 * cin, stream_k, dtype, nullptr, concurrent);   // the launch's own choice
   const bool small = cfg == C64x64 || cout % 64 || m <= 4096;
   snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, 2, 2, %d, true>", dtype == DT_BF16 ? "__bf16" : "float",
-           small ? "64, 64" : "128, 64", casync_opts().gemm_pipe != 0 ? 3 : 2);
+             small ? "64, 64" : "128, 64", casync_opts().gemm_pipe != 0 ? 3 : 2);
   return buf;
 }
 

@@ -17,6 +17,7 @@ struct OptField {
 const OptField kFields[] = {
     {"lanes", &CasyncOptions::lanes},
     {"trunk_lanes", &CasyncOptions::trunk_lanes},
+    {"lane_skew", &CasyncOptions::lane_skew},
     {"overlap", &CasyncOptions::overlap},
     {"gemm_streamk", &CasyncOptions::gemm_streamk},
     {"gemm_glds", &CasyncOptions::gemm_glds},
@@ -28,12 +29,12 @@ const OptField kFields[] = {
     {"fuse_ir", &CasyncOptions::fuse_ir},
     {"fuse_up", &CasyncOptions::fuse_up},
     {"fuse_min_hw", &CasyncOptions::fuse_min_hw},
+    {"ir_ws", &CasyncOptions::ir_ws},
     {"fuse_q", &CasyncOptions::fuse_q},
     {"dw_lds", &CasyncOptions::dw_lds},
     {"dw_lds_bytes", &CasyncOptions::dw_lds_bytes},
     {"conv_im2col", &CasyncOptions::conv_im2col},
     {"att_nz", &CasyncOptions::att_nz},
-    {"dbg_noload", &CasyncOptions::dbg_noload},
 };
 
 thread_local const CasyncOptions* t_current = nullptr;

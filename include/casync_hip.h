@@ -148,6 +148,9 @@ int casync_op_pw_gemm(const void* a, int lda, const void* w, const float* bias,
 /* Diagnostic (tools/experiments/gemm_timeline.py): the casync_op_pw_gemm calls this thread makes next
  * write 8 timestamp words per workgroup into dev_words (NULL = off).  Never used by the engine.  */
 int casync_debug_gemm_stamps(void* dev_words);
+/* Same for the fused inverted-residual kernel (fp32): 5 words per workgroup (first 4096 workgroups) = shader
+ * cycles of wave 0 in prologue / P1 / P2 / P3 / epilogue.  tools/experiments/ir_timeline.py.              */
+int casync_debug_ir_stamps(void* dev_words);
 /* nn.Conv2d(k=3, bias) + folded BN + LeakyReLU of the audio encoder (conv3: stride 2 pad 1, conv5: stride 2
  * pad 3; module/unet.py:161-168) as an implicit GEMM: in [B,H,W,cin] NHWC, w [cout][(ky,kx,cin)],
  * out [B,Ho,Wo,cout].  cin % (128 B / elem) == 0, cout % 64 == 0. */

@@ -17,9 +17,14 @@ DEV = torch.device("cuda:0")
 
 
 def time_ms(fn, iters):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
+    # warm the clock as well as the caches: after ~1 s idle the chip restarts at ~2.1 GHz and takes tens of
+    # ms of load to reach its 2.39 GHz (profiles/r2_mfma_clock.txt); ~0.2 s of the op itself first
+    import time
+    t_end = time.perf_counter() + 0.2
+    while time.perf_counter() < t_end:
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters):
