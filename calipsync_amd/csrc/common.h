@@ -59,7 +59,6 @@ struct CasyncOptions {
   int fuse_ir = 1;           // CASYNC_FUSE_IR: fused inverted-residual kernel
   int fuse_up = 1;           // CASYNC_FUSE_UP: bilinear upsample folded into up3/up4
   int fuse_min_hw = 32;      // CASYNC_FUSE_MIN_HW: lowest resolution the fused kernel is used at
-  int ir_ws = 0;             // CASYNC_IR_WS: wave-specialised fused inverted residual (fp32): MFMA waves + depthwise waves
   int fuse_q = 1;            // CASYNC_FUSE_Q: query projection as 64 extra columns of the p_1 GEMM
   int dw_lds = 1;            // CASYNC_DW_LDS: LDS-slab depthwise kernel
   int dw_lds_bytes = 32768;  // CASYNC_DW_LDS_BYTES

@@ -90,7 +90,18 @@ struct IRGeom {
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ float lrelu_max(float v) { return fmaxf(v, v * CASYNC_LRELU_SLOPE); }
+// max(v, slope*v) on four values in 2 + 4 VALU instructions: the multiply as two v_pk_mul_f32, the maximum as
+// a bare v_max_f32 (fmaxf() on an MFMA result costs a third instruction per value, the sNaN-quieting
+// v_max v,v,v; fp32 MFMA and VALU instructions of a SIMD do not overlap, so every one of them is MFMA time lost)
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x4 lrelu4(f32x4 v) {
+  const f32x4 s = v * CASYNC_LRELU_SLOPE;
+  return f32x4{vmax_raw(v.x, s.x), vmax_raw(v.y, s.y), vmax_raw(v.z, s.z), vmax_raw(v.w, s.w)};
+}
 
 // Waves per SIMD the register allocator must leave room for (= co-resident workgroups per
 // CU): A fragments + both accumulator sets + ~70 registers of addressing / staging.
@@ -277,18 +288,15 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
       for (int i = 0; i < G::MT1; ++i) {
         const int hp = 16 * (wave * G::MT1 + i) + l15;     // this lane's halo pixel
         if (hp < G::HP) {
-          float m = 1.f;
+          bool inside = true;   // the depthwise conv zero-pads E: halo pixels outside the image are 0, not lrelu(b1)
           if (border) {
             const int hy = hp / G::IW, hx = hp - hy * G::IW;
             const int iy = iy0 + hy, ix = ix0 + hx;
-            m = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? 1.f : 0.f;
+            inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
           }
 #pragma unroll
-          for (int n = 0; n < G::NT1; ++n) {
-            f32x4 v = acc[i][n];
-            v.x = m * lrelu_max(v.x); v.y = m * lrelu_max(v.y); v.z = m * lrelu_max(v.z); v.w = m * lrelu_max(v.w);
-            *reinterpret_cast<f32x4*>(sE + hp * CC + 16 * n + 4 * q) = v;
-          }
+          for (int n = 0; n < G::NT1; ++n)
+            *reinterpret_cast<f32x4*>(sE + hp * CC + 16 * n + 4 * q) = inside ? lrelu4(acc[i][n]) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
     }
@@ -330,9 +338,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
       }
 #pragma unroll
       for (int j = 0; j < NPX; ++j) {
-        f32x4 v = a[j];
-        v.x = lrelu_max(v.x); v.y = lrelu_max(v.y); v.z = lrelu_max(v.z); v.w = lrelu_max(v.w);
-        *reinterpret_cast<f32x4*>(sD + xs<CC>((py0 + j) * TW + px, c4)) = v;
+        *reinterpret_cast<f32x4*>(sD + xs<CC>((py0 + j) * TW + px, c4)) = lrelu4(a[j]);
       }
     }
     __syncthreads();  // D complete (and the parked weights are visible)
@@ -376,9 +382,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
 #pragma unroll
       for (int i = 0; i < G::MT3; ++i) {
         const int p = 16 * (wave * G::MT3 + i) + l15;      // acc3 rows = 4 consecutive output channels
-        f32x4 v = acc3[i][n0 + nn] + bias;
-        v.x = lrelu_max(v.x); v.y = lrelu_max(v.y); v.z = lrelu_max(v.z); v.w = lrelu_max(v.w);
-        *reinterpret_cast<f32x4*>(sO + p * G::LDO + 16 * nn + 4 * q) = v;
+        *reinterpret_cast<f32x4*>(sO + p * G::LDO + 16 * nn + 4 * q) = lrelu4(acc3[i][n0 + nn] + bias);
       }
     }
     __syncthreads();
@@ -402,332 +406,6 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
       const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
       if (wg < 4096)
         for (int k = 0; k < 5; ++k) stamps[wg * 8 + k] = t_phase[k];
-    }
-  }
-}
-
-// =====================================================================================
-// Wave-specialised fp32 variant (default for the fp32 engine).  Same arithmetic, same tiles, but 8 waves:
-// waves 0-3 ("M") do nothing but the two MFMA phases, waves 4-7 ("V") do the depthwise phase and all the
-// weight staging, and the phases of DIFFERENT chunks run side by side:
-//
-//   step s:   M waves: P1(chunk s) -> E[s&1],  then P3(chunk s-2) from D[(s-2)&1]
-//             V waves: park weights(s+1), fetch weights(s+2),  P2(chunk s-1): E[(s-1)&1] -> D[(s-1)&1]
-//   one workgroup barrier per step.
-//
-// Why (tools/experiments/ir_timeline.py, up4.0 at three workgroups per CU): in the single-role kernel a
-// chunk costs a wave 3,945 (P1) + 2,742 (P2, MFMA idle for this workgroup) + 804 (P3) cycles for 2,048
-// cycles of MFMA issue, and prologue + epilogue (21 % of a workgroup's life) have no MFMA at all: the matrix
-// pipes end up 58-65 % busy.  Here a workgroup ALONE keeps its matrix waves busy (their only wait is the
-// step barrier; the V waves' ~700 cycles of VALU/LDS per step fit beside 2,048 cycles of MFMA), so a
-// co-resident workgroup's prologue / epilogue are covered by the other's MFMAs.
-// LDS: E and D double-buffered; W1c/b1 in 2 slots (used one step after they are parked), W2c/Wd/bd in 4 slots
-// (Wd is used one step later, W2c two).  ~67 KB for every instance of the plan -> two workgroups per CU.
-// =====================================================================================
-template <int CIN, int COUT, int STRIDE, int CC>
-struct IRGeomWS {
-  using G = IRGeom<CIN, COUT, STRIDE, CC>;
-  static constexpr int ABUF = CC * CIN + CC;                 // W1c [CC][CIN], b1 [CC]
-  static constexpr int BBUF = COUT * CC + 9 * CC + CC;       // W2c [COUT][CC], Wd [9][CC], bd [CC]
-  static constexpr int bW2 = 0, bWd = COUT * CC, bBd = bWd + 9 * CC;
-  static constexpr int oE = 0, oD = oE + 2 * G::HP * CC, oA = oD + 2 * G::OP * CC, oB = oA + 2 * ABUF;
-  static constexpr int total = oB + 4 * BBUF;
-  static_assert(G::OP * G::LDO <= oA, "epilogue staging must fit in E+D");
-  static_assert((G::HP * CC) % 4 == 0 && (G::OP * CC) % 4 == 0 && ABUF % 4 == 0 && BBUF % 4 == 0, "16-B aligned carve");
-  static_assert(total * 4 <= 160 * 1024, "LDS budget");
-  // registers of the matrix waves: A fragments + both accumulator sets + addressing
-  static constexpr int est = 4 * (G::MT1 * G::KG + G::MT3 * G::NT3 + G::MT1 * G::NT1) + 48;
-  static constexpr int min_waves = est <= 128 && 2 * total * 4 <= 160 * 1024 ? 4 : 2;   // waves per SIMD = 2 x workgroups per CU
-};
-
-template <int CIN, int CE, int COUT, int STRIDE, int CC, bool UPS>
-__global__ __launch_bounds__(512, (IRGeomWS<CIN, COUT, STRIDE, CC>::min_waves)) void ir_fused_ws_kernel(
-    const float* __restrict__ lo, int ld_lo, int c_lo, const float* __restrict__ in, int ld_in,
-    const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ wd,
-    const float* __restrict__ bd, const float* __restrict__ w2, const float* __restrict__ b2,
-    float* __restrict__ out, int ld_out, int H, int W, int Ho, int Wo, int res) {
-  using G = IRGeom<CIN, COUT, STRIDE, CC>;
-  using GW = IRGeomWS<CIN, COUT, STRIDE, CC>;
-  constexpr int NCH = CE / CC;
-  extern __shared__ __attribute__((aligned(16))) float smem_ws[];
-  float* sE = smem_ws + GW::oE;
-  float* sD = smem_ws + GW::oD;
-  float* sA = smem_ws + GW::oA;
-  float* sB = smem_ws + GW::oB;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool is_m = wave < 4;
-  const int l15 = lane & 15, q = lane >> 4;
-  const int b = blockIdx.z, oy0 = blockIdx.y * G::TH, ox0 = blockIdx.x * TW;
-  const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
-  const float* inb = in + (size_t)b * H * W * ld_in;
-  const bool border = iy0 < 0 || ix0 < 0 || iy0 + G::IH > H || ix0 + G::IW > W;
-
-  // ---- V waves: weight chunk global -> registers (wload) -> LDS (wstore) ----
-  const int vt = tid - 256;   // 0..255 on the V waves
-  f32x4 rw1[G::NW1], rw2[G::NW2], rwd[G::NWD];
-  auto wload = [&](int ce0) {
-#pragma unroll
-    for (int j = 0; j < G::NW1; ++j) {
-      const int idx = vt + 256 * j;
-      if (G::NW1 * 256 == CC * CIN / 4 || idx < CC * CIN / 4)
-        rw1[j] = *reinterpret_cast<const f32x4*>(w1 + (size_t)ce0 * CIN + idx * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < G::NW2; ++j) {
-      const int idx = vt + 256 * j;
-      if (idx < COUT * CC / 4) {
-        const int r = idx / (CC / 4), c4 = (idx - r * (CC / 4)) * 4;
-        rw2[j] = *reinterpret_cast<const f32x4*>(w2 + (size_t)r * CE + ce0 + c4);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < G::NWD; ++j) {
-      const int idx = vt + 256 * j;
-      if (idx < 11 * CC / 4) {
-        const int t = idx / (CC / 4), c4 = (idx - t * (CC / 4)) * 4;   // t: 0..8 taps, 9 = b1, 10 = bd
-        const float* src = t < 9 ? wd + (size_t)t * CE : (t == 9 ? b1 : bd);
-        rwd[j] = *reinterpret_cast<const f32x4*>(src + ce0 + c4);
-      }
-    }
-  };
-  auto wstore = [&](int ch) {
-    float* wa = sA + (ch & 1) * GW::ABUF;
-    float* wbB = sB + (ch & 3) * GW::BBUF;
-#pragma unroll
-    for (int j = 0; j < G::NW1; ++j) {
-      const int idx = vt + 256 * j;
-      if (G::NW1 * 256 == CC * CIN / 4 || idx < CC * CIN / 4) {
-        const int r = idx / (CIN / 4), c4 = (idx - r * (CIN / 4)) * 4;
-        *reinterpret_cast<f32x4*>(wa + xs<CIN>(r, c4)) = rw1[j];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < G::NW2; ++j) {
-      const int idx = vt + 256 * j;
-      if (idx < COUT * CC / 4) {
-        const int r = idx / (CC / 4), c4 = (idx - r * (CC / 4)) * 4;
-        *reinterpret_cast<f32x4*>(wbB + GW::bW2 + xs<CC>(r, c4)) = rw2[j];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < G::NWD; ++j) {
-      const int idx = vt + 256 * j;
-      if (idx < 11 * CC / 4) {
-        const int t = idx / (CC / 4), c4 = (idx - t * (CC / 4)) * 4;
-        float* dst = t < 9 ? wbB + GW::bWd + t * CC : (t == 9 ? wa + CC * CIN : wbB + GW::bBd);
-        *reinterpret_cast<f32x4*>(dst + c4) = rwd[j];
-      }
-    }
-  };
-
-  // ---- prologue: M waves fetch their halo rows' A fragments, V waves stage chunk 0 and fetch chunk 1 ----
-  f32x4 fa[G::MT1][G::KG];
-  if (is_m) {
-#pragma unroll
-    for (int i = 0; i < G::MT1; ++i) {
-      const int hp = 16 * (wave * G::MT1 + i) + l15;
-      const int hy = hp / G::IW, hx = hp - hy * G::IW;
-      const int iy = iy0 + hy, ix = ix0 + hx;
-      const bool ok = hp < G::HP && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      const float* src = inb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * ld_in + 4 * q;
-      if constexpr (UPS) {
-        // same arithmetic as upsample2x_kernel / ATen: src = dst*(in-1)/(out-1), l1 = frac, l0 = 1-l1
-        const int Hl = H >> 1, Wl = W >> 1;
-        const float sy = (float)(Hl - 1) / (float)(H - 1), sx = (float)(Wl - 1) / (float)(W - 1);
-        const float fy = sy * (ok ? iy : 0), fx = sx * (ok ? ix : 0);
-        const int y0 = (int)fy, x0 = (int)fx;
-        const int y1 = y0 + (y0 < Hl - 1), x1 = x0 + (x0 < Wl - 1);
-        const float ly1 = fy - y0, lx1 = fx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-        const float* lb = lo + (size_t)b * Hl * Wl * ld_lo + 4 * q;
-        const float* p00 = lb + ((size_t)y0 * Wl + x0) * ld_lo;
-        const float* p01 = lb + ((size_t)y0 * Wl + x1) * ld_lo;
-        const float* p10 = lb + ((size_t)y1 * Wl + x0) * ld_lo;
-        const float* p11 = lb + ((size_t)y1 * Wl + x1) * ld_lo;
-#pragma unroll
-        for (int g = 0; g < G::KG; ++g) {
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (ok) {
-            if (16 * g < c_lo) {
-              const f32x4 v00 = ld4(p00 + 16 * g);
-              const f32x4 v01 = ld4(p01 + 16 * g);
-              const f32x4 v10 = ld4(p10 + 16 * g);
-              const f32x4 v11 = ld4(p11 + 16 * g);
-              v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
-            } else {
-              v = ld4(src + 16 * g);
-            }
-          }
-          fa[i][g] = v;
-        }
-      } else {
-#pragma unroll
-        for (int g = 0; g < G::KG; ++g) fa[i][g] = ok ? ld4(src + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
-  } else {
-    wload(0);
-    wstore(0);
-    if (NCH > 1) wload(CC);
-  }
-  __syncthreads();
-
-  f32x4 acc3[G::MT3][G::NT3];
-#pragma unroll
-  for (int i = 0; i < G::MT3; ++i)
-#pragma unroll
-    for (int n = 0; n < G::NT3; ++n) acc3[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // one loop per role (not one loop with a role branch inside): the matrix waves' fragments and the vector
-  // waves' staging registers then never share a live range, and both roles fit 128 registers
-  if (is_m) {
-#pragma unroll 1
-    for (int s = 0; s < NCH + 2; ++s) {
-      if (s < NCH) {
-        // ---- P1(s): expand GEMM over the halo -> E[s&1]; weight chunk = MFMA A operand, pixels = B operand,
-        //      so a lane ends up with 4 consecutive channels of one pixel; bias = initial accumulator ----
-        const float* wa = sA + (s & 1) * GW::ABUF;
-        float* e_out = sE + (s & 1) * (G::HP * CC);
-        f32x4 acc[G::MT1][G::NT1];
-#pragma unroll
-        for (int n = 0; n < G::NT1; ++n) {
-          const f32x4 bias = *reinterpret_cast<const f32x4*>(wa + CC * CIN + 16 * n + 4 * q);
-#pragma unroll
-          for (int i = 0; i < G::MT1; ++i) acc[i][n] = bias;
-        }
-#pragma unroll
-        for (int g = 0; g < G::KG; ++g) {
-          f32x4 fb[G::NT1];
-#pragma unroll
-          for (int n = 0; n < G::NT1; ++n)
-            fb[n] = *reinterpret_cast<const f32x4*>(wa + xs<CIN>(16 * n + l15, 16 * g + 4 * q));
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < G::MT1; ++i)
-#pragma unroll
-              for (int n = 0; n < G::NT1; ++n) acc[i][n] = mfma16(fb[n][t], fa[i][g][t], acc[i][n]);
-        }
-#pragma unroll
-        for (int i = 0; i < G::MT1; ++i) {
-          const int hp = 16 * (wave * G::MT1 + i) + l15;
-          if (hp < G::HP) {
-            float m = 1.f;
-            if (border) {
-              const int hy = hp / G::IW, hx = hp - hy * G::IW;
-              const int iy = iy0 + hy, ix = ix0 + hx;
-              m = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? 1.f : 0.f;
-            }
-#pragma unroll
-            for (int n = 0; n < G::NT1; ++n) {
-              f32x4 v = acc[i][n];
-              v.x = m * lrelu_max(v.x); v.y = m * lrelu_max(v.y); v.z = m * lrelu_max(v.z); v.w = m * lrelu_max(v.w);
-              *reinterpret_cast<f32x4*>(e_out + hp * CC + 16 * n + 4 * q) = v;
-            }
-          }
-        }
-      }
-      if (s >= 2) {
-        // ---- P3(s-2): project GEMM, acc3 += D[(s-2)&1] x W2c(s-2)^T ----
-        const float* d_in = sD + (s & 1) * (G::OP * CC);
-        const float* w2c = sB + ((s - 2) & 3) * GW::BBUF + GW::bW2;
-#pragma unroll
-        for (int g = 0; g < CC / 16; ++g) {
-          f32x4 fd[G::MT3], fw[G::NT3];
-#pragma unroll
-          for (int i = 0; i < G::MT3; ++i)
-            fd[i] = *reinterpret_cast<const f32x4*>(d_in + xs<CC>(16 * (wave * G::MT3 + i) + l15, 16 * g + 4 * q));
-#pragma unroll
-          for (int n = 0; n < G::NT3; ++n)
-            fw[n] = *reinterpret_cast<const f32x4*>(w2c + xs<CC>(16 * n + l15, 16 * g + 4 * q));
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < G::MT3; ++i)
-#pragma unroll
-              for (int n = 0; n < G::NT3; ++n) acc3[i][n] = mfma16(fw[n][t], fd[i][t], acc3[i][n]);   // D[cout][pixel]
-        }
-      }
-      __syncthreads();   // step boundary (matched one for one by the vector waves' loop below)
-    }
-  } else {
-#pragma unroll 1
-    for (int s = 0; s < NCH + 2; ++s) {
-      if (s + 1 < NCH) {
-        wstore(s + 1);                          // park the next chunk's weights
-        if (s + 2 < NCH) wload((s + 2) * CC);   // and start fetching the one after
-      }
-      if (s >= 1 && s <= NCH) {
-        // ---- P2(s-1): depthwise 3x3 over E[(s-1)&1] -> D[(s-1)&1]; thread = 4 channels x NPX pixels stacked in y ----
-        const int c = s - 1;
-        const float* e_in = sE + (c & 1) * (G::HP * CC);
-        float* d_out = sD + (c & 1) * (G::OP * CC);
-        const float* wt_b = sB + (c & 3) * GW::BBUF;
-        constexpr int TPP = CC / 4, PPI = 256 / TPP, NPX = G::OP / PPI, NROW = (NPX - 1) * STRIDE + 3;
-        static_assert(PPI % TW == 0 && G::TH % NPX == 0, "P2 thread map");
-        const int c4 = (vt % TPP) * 4, p0 = vt / TPP;
-        const int px = p0 % TW, py0 = (p0 / TW) * NPX;
-        const float* eb = e_in + ((py0 * STRIDE) * G::IW + px * STRIDE) * CC + c4;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(wt_b + GW::bBd + c4);
-        f32x4 a[NPX];
-#pragma unroll
-        for (int j = 0; j < NPX; ++j) a[j] = bv;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          f32x4 wt[3];
-#pragma unroll
-          for (int ky = 0; ky < 3; ++ky) wt[ky] = *reinterpret_cast<const f32x4*>(wt_b + GW::bWd + (ky * 3 + kx) * CC + c4);
-#pragma unroll
-          for (int r = 0; r < NROW; ++r) {
-            const f32x4 e = *reinterpret_cast<const f32x4*>(eb + (r * G::IW + kx) * CC);
-#pragma unroll
-            for (int j = 0; j < NPX; ++j) {
-              const int ky = r - j * STRIDE;
-              if (ky >= 0 && ky < 3) a[j] += e * wt[ky];
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < NPX; ++j) {
-          f32x4 v = a[j];
-          v.x = lrelu_max(v.x); v.y = lrelu_max(v.y); v.z = lrelu_max(v.z); v.w = lrelu_max(v.w);
-          *reinterpret_cast<f32x4*>(d_out + xs<CC>((py0 + j) * TW + px, c4)) = v;
-        }
-      }
-      __syncthreads();   // step boundary: E[s&1] / D[(s-1)&1] / parked weights complete, everything they replace is consumed
-    }
-  }
-
-  // ---- epilogue: + b2, LReLU -> LDS staging (over E/D, 32 columns at a time) -> coalesced NHWC rows (+ residual) ----
-  float* sO = sE;
-  float* outb = out + (size_t)b * Ho * Wo * ld_out;
-#pragma unroll
-  for (int n0 = 0; n0 < G::NT3; n0 += 2) {
-    if (n0) __syncthreads();
-    if (is_m) {
-#pragma unroll
-      for (int nn = 0; nn < 2; ++nn) {
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(b2 + 16 * (n0 + nn) + 4 * q);
-#pragma unroll
-        for (int i = 0; i < G::MT3; ++i) {
-          const int p = 16 * (wave * G::MT3 + i) + l15;
-          f32x4 v = acc3[i][n0 + nn] + bias;
-          v.x = lrelu_max(v.x); v.y = lrelu_max(v.y); v.z = lrelu_max(v.z); v.w = lrelu_max(v.w);
-          *reinterpret_cast<f32x4*>(sO + p * G::LDO + 16 * nn + 4 * q) = v;
-        }
-      }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < G::OP * 8; idx += 512) {
-      const int p = idx >> 3, c4 = (idx & 7) * 4;
-      const int py = p / TW, px = p - py * TW;
-      const int oy = oy0 + py, ox = ox0 + px;
-      if (oy < Ho && ox < Wo) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(sO + p * G::LDO + c4);
-        const int c = 16 * n0 + c4;
-        if (res) v += ld4(inb + ((size_t)oy * W + ox) * ld_in + c);
-        st4(outb + ((size_t)oy * Wo + ox) * ld_out + c, v);
-      }
     }
   }
 }
@@ -917,17 +595,18 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
       for (int i = 0; i < G::MT1; ++i) {
         const int hp = 16 * (wave * G::MT1 + i) + l15;     // this lane's halo pixel
         if (hp < G::HP) {
-          float m = 1.f;
+          bool inside = true;
           if (border) {
             const int hy = hp / G::IW, hx = hp - hy * G::IW;
             const int iy = iy0 + hy, ix = ix0 + hx;
-            m = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? 1.f : 0.f;
+            inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
           }
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
+            const f32x4 a = inside ? lrelu4(acc[i][n]) : f32x4{0.f, 0.f, 0.f, 0.f};
             bf16x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(m * lrelu_max(acc[i][n][r]));
+            for (int r = 0; r < 4; ++r) v[r] = (bf16_t)a[r];
             *reinterpret_cast<bf16x4*>(sE + (hp * CC + 16 * n + 4 * q) * 2) = v;
           }
         }
@@ -965,11 +644,12 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
       }
 #pragma unroll
       for (int j = 0; j < NPX; ++j) {
+        const f32x4 l0 = lrelu4(a0[j]), l1 = lrelu4(a1[j]);
         bf16x8 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = (bf16_t)lrelu_max(a0[j][e]);
-          v[e + 4] = (bf16_t)lrelu_max(a1[j][e]);
+          v[e] = (bf16_t)l0[e];
+          v[e + 4] = (bf16_t)l1[e];
         }
         *reinterpret_cast<bf16x8*>(sD + xsb<64>(p0 + PPI * j, c8 * 2)) = v;
       }
@@ -1007,9 +687,7 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
 #pragma unroll
       for (int i = 0; i < G::MT3; ++i) {
         const int p = 16 * (wave * G::MT3 + i) + l15;
-        f32x4 v = acc3[i][n0 + nn] + bias;
-        v.x = lrelu_max(v.x); v.y = lrelu_max(v.y); v.z = lrelu_max(v.z); v.w = lrelu_max(v.w);
-        *reinterpret_cast<f32x4*>(sO + p * G::LDO + 16 * nn + 4 * q) = v;
+        *reinterpret_cast<f32x4*>(sO + p * G::LDO + 16 * nn + 4 * q) = lrelu4(acc3[i][n0 + nn] + bias);
       }
     }
     __syncthreads();
@@ -1045,33 +723,11 @@ int launch_inst_b(const bf16_t* lo, int ld_lo, int c_lo, const bf16_t* in, int l
   return CASYNC_OK;
 }
 
-template <int CIN, int CE, int COUT, int STRIDE, int CC, bool UPS>
-int launch_inst_ws(const float* lo, int ld_lo, int c_lo, const float* in, int ld_in, const float* w1, const float* b1,
-                   const float* wd, const float* bd, const float* w2, const float* b2, float* out, int ld_out,
-                   int batch, int h, int w, int res, hipStream_t stream) {
-  using G = IRGeom<CIN, COUT, STRIDE, CC>;
-  using GW = IRGeomWS<CIN, COUT, STRIDE, CC>;
-  constexpr size_t lds = (size_t)GW::total * sizeof(float);
-  auto kern = ir_fused_ws_kernel<CIN, CE, COUT, STRIDE, CC, UPS>;
-  static unsigned long long attr_once = 0;
-  if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)lds)) return st;
-  const int ho = (h + 2 - 3) / STRIDE + 1, wo = (w + 2 - 3) / STRIDE + 1;
-  dim3 grid((wo + TW - 1) / TW, (ho + G::TH - 1) / G::TH, batch);
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out,
-                     h, w, ho, wo, res);
-  CASYNC_CHECK_HIP(hipGetLastError());
-  return CASYNC_OK;
-}
-
 template <typename T, int CIN, int CE, int COUT, int STRIDE, int CC, bool UPS>
 int launch_inst_t(const T* lo, int ld_lo, int c_lo, const T* in, int ld_in, const float* w1, const float* b1,
                   const float* wd, const float* bd, const float* w2, const float* b2, T* out, int ld_out,
                   int batch, int h, int w, int res, hipStream_t stream) {
   using G = IRGeom<CIN, COUT, STRIDE, CC>;
-  if constexpr (sizeof(T) == 4)
-    if (casync_opts().ir_ws)
-      return launch_inst_ws<CIN, CE, COUT, STRIDE, CC, UPS>(lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out,
-                                                            batch, h, w, res, stream);
   constexpr size_t lds = (size_t)G::total * sizeof(float);
   auto kern = ir_fused_kernel<T, CIN, CE, COUT, STRIDE, CC, UPS>;
   static unsigned long long attr_once = 0;
@@ -1147,8 +803,6 @@ const char* ir_fused_kernel_name(int cin, int cout, int stride, int dtype) {
   static thread_local char buf[64];
   if (dtype == DT_BF16)
     snprintf(buf, sizeof(buf), "ir_fused_bf16_kernel<%d, %d, %d, %d>", cin, 2 * cin, cout, stride);
-  else if (casync_opts().ir_ws)
-    snprintf(buf, sizeof(buf), "ir_fused_ws_kernel<%d, %d, %d, %d, 16>", cin, 2 * cin, cout, stride);
   else
     snprintf(buf, sizeof(buf), "ir_fused_kernel<float, %d, %d, %d, %d, 16>", cin, 2 * cin, cout, stride);
   return buf;

@@ -29,7 +29,6 @@ const OptField kFields[] = {
     {"fuse_ir", &CasyncOptions::fuse_ir},
     {"fuse_up", &CasyncOptions::fuse_up},
     {"fuse_min_hw", &CasyncOptions::fuse_min_hw},
-    {"ir_ws", &CasyncOptions::ir_ws},
     {"fuse_q", &CasyncOptions::fuse_q},
     {"dw_lds", &CasyncOptions::dw_lds},
     {"dw_lds_bytes", &CasyncOptions::dw_lds_bytes},

@@ -5,7 +5,7 @@
 #    bench.py's roofline block is measured in) and of the timed two-lane run itself;
 # 2. PMC passes (FETCH_SIZE, WRITE_SIZE separately, no trace domains mixed in) of the replay
 set -e
-tag=${1:-r1}
+tag=${1:-r2}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
