@@ -54,6 +54,7 @@ struct CasyncOptions {
   int gemm_cfg = -1;         // CASYNC_GEMM_CFG: force one tile configuration
   int gemm_pipe = 0;         // CASYNC_GEMM_PIPE: stages of the software-pipelined LDS-DMA ring, 3..6 (0 = the round-1 loop)
   int gemm_persist = 1;      // CASYNC_GEMM_PERSIST: persistent grid of the register-staged GEMM
+  int lane_streamk = 0;      // CASYNC_LANE_STREAMK: stream-K also when two or more lanes run side by side (the other lane fills tails otherwise)
   int gemm_conc = 3;         // CASYNC_GEMM_CONC: tile policy when lanes share the chip
   int gemm_conc_tiles = 2048;  // CASYNC_GEMM_CONC_TILES
   int fuse_ir = 1;           // CASYNC_FUSE_IR: fused inverted-residual kernel
@@ -176,7 +177,7 @@ int launch_dw3x3(const void* in, const float* w, const float* bias, void* out, i
                  int wdt, int c, int stride, hipStream_t stream, int dtype = DT_F32);
 const char* dw3x3_kernel_name(int h, int wdt, int c, int stride, int dtype = DT_F32);
 bool ir_fused_supported(int cin, int cout, int stride);
-const char* ir_fused_kernel_name(int cin, int cout, int stride, int dtype = DT_F32);
+const char* ir_fused_kernel_name(int cin, int cout, int stride, int dtype = DT_F32, bool ups = false);   // as rocprofv3 prints it
 bool ir_fused_up_supported(int cin, int cout);
 int launch_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const void* w1,
                        const float* b1, const float* wd, const float* bd, const void* w2,

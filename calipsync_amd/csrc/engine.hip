@@ -576,7 +576,7 @@ struct Plan {
         // bilinear x2 folded into the fused block's input load: up(x) is never materialised
         const std::string p = b0.prefix;
         const double m = (double)B * 4 * hw * hw;
-        r.run((p + ".upfused").c_str(), ir_fused_kernel_name(b0.cin, b0.cout, 1, dt()),
+        r.run((p + ".upfused").c_str(), ir_fused_kernel_name(b0.cin, b0.cout, 1, dt(), true),
               2.0 * m * (b0.cin * b0.cexp() + 9.0 * b0.cexp() + b0.cexp() * b0.cout),
               dtype_size(dt()) * (m / 4 * c + m * c + m * b0.cout), [&] {
                 return launch_ir_fused_up(lo, c, c, cat[i], cc, e.WG(p + ".pw1.w"), e.W(p + ".pw1.b"),
@@ -881,8 +881,9 @@ static int run_forward(casync_handle h, const FwdArgs& A, hipStream_t caller, st
     forked = true;
   }
   const bool conc = lanes > 1;
+  const bool lane_sk = !conc || o.lane_streamk != 0;
   for (int l = 0; l < lanes; ++l)
-    if (int st = run_phase(0, l, b0s[l], bls[l], !conc, conc)) return fail(st);
+    if (int st = run_phase(0, l, b0s[l], bls[l], lane_sk, conc)) return fail(st);
   if (hybrid) {
     if (!serial)
       for (int l = 1; l < lanes; ++l) {
@@ -896,10 +897,10 @@ static int run_forward(casync_handle h, const FwdArgs& A, hipStream_t caller, st
     }
   } else {
     for (int l = 0; l < lanes; ++l)
-      if (int st = run_phase(1, l, b0s[l], bls[l], !conc, conc)) return fail(st);
+      if (int st = run_phase(1, l, b0s[l], bls[l], lane_sk, conc)) return fail(st);
   }
   for (int l = 0; l < lanes; ++l)
-    if (int st = run_phase(2, l, b0s[l], bls[l], !conc, conc)) return fail(st);
+    if (int st = run_phase(2, l, b0s[l], bls[l], lane_sk, conc)) return fail(st);
   if (lanes > 1 && !serial)
     for (int l = 1; l < lanes; ++l) {
       FWD_HIP(hipEventRecord(h->ev_done[l], h->lane_s[l]));

@@ -799,12 +799,12 @@ int launch_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, int 
   return CASYNC_ERR_ARG;
 }
 
-const char* ir_fused_kernel_name(int cin, int cout, int stride, int dtype) {
+const char* ir_fused_kernel_name(int cin, int cout, int stride, int dtype, bool ups) {
   static thread_local char buf[64];
   if (dtype == DT_BF16)
-    snprintf(buf, sizeof(buf), "ir_fused_bf16_kernel<%d, %d, %d, %d>", cin, 2 * cin, cout, stride);
+    snprintf(buf, sizeof(buf), "ir_fused_bf16_kernel<%d, %d, %d, %d, %s>", cin, 2 * cin, cout, stride, ups ? "true" : "false");
   else
-    snprintf(buf, sizeof(buf), "ir_fused_kernel<float, %d, %d, %d, %d, 16>", cin, 2 * cin, cout, stride);
+    snprintf(buf, sizeof(buf), "ir_fused_kernel<float, %d, %d, %d, %d, 16, %s>", cin, 2 * cin, cout, stride, ups ? "true" : "false");
   return buf;
 }
 

@@ -24,6 +24,7 @@ const OptField kFields[] = {
     {"gemm_cfg", &CasyncOptions::gemm_cfg},
     {"gemm_pipe", &CasyncOptions::gemm_pipe},
     {"gemm_persist", &CasyncOptions::gemm_persist},
+    {"lane_streamk", &CasyncOptions::lane_streamk},
     {"gemm_conc", &CasyncOptions::gemm_conc},
     {"gemm_conc_tiles", &CasyncOptions::gemm_conc_tiles},
     {"fuse_ir", &CasyncOptions::fuse_ir},

@@ -91,6 +91,41 @@ def make_state_dict(seed: int = WEIGHT_SEED) -> Dict[str, np.ndarray]:
     return sd
 
 
+# Second fixture, "G1.2-B" (tests/golden/unet_g12b_b3.npz): other seeds, and the corners the first recipe leaves
+# out -- attention gammas of both signs and very different sizes, BatchNorm channels whose running variance
+# (1e-3) is small enough for eps = 1e-5 to matter in the fold, audio features four times larger, an odd batch.
+WEIGHT_SEED_B = 0x5EED0B
+INPUT_SEED_B = 0x1B0B
+GAMMAS_B = (0.5, -0.75, 1.25, 0.1)
+SMALL_VAR_B = 1e-3
+AUDIO_SCALE_B = 4.0
+BATCH_B = 3
+
+
+def make_state_dict_b() -> Dict[str, np.ndarray]:
+    """The G1.2-B weights: ``make_state_dict(WEIGHT_SEED_B)`` with GAMMAS_B on the four cross-attention blocks
+    and every 7th BatchNorm channel (offset by the layer) at running_var = 1e-3; the BatchNorm weight of those
+    channels is scaled by sqrt(1e-3) so that activations keep their size through the 60-odd layers."""
+    sd = make_state_dict(WEIGHT_SEED_B)
+    g = 0
+    for key, shape, _dtype, role in arch.manifest():
+        if role == "gamma":
+            sd[key] = np.full(shape, GAMMAS_B[g], dtype=np.float32)
+            g += 1
+        elif role == "bn_var":
+            sel = np.arange(shape[0]) % 7 == _stream(key) % 7
+            sd[key] = np.where(sel, np.float32(SMALL_VAR_B), sd[key]).astype(np.float32)
+            wkey = key[: -len("running_var")] + "weight"
+            sd[wkey] = np.where(sel, sd[wkey] * np.float32(np.sqrt(SMALL_VAR_B)), sd[wkey]).astype(np.float32)
+    assert g == len(GAMMAS_B)
+    return sd
+
+
+def make_inputs_b(batch: int = BATCH_B) -> Tuple[np.ndarray, np.ndarray]:
+    x, a = make_inputs(batch, INPUT_SEED_B)
+    return x, (a * np.float32(AUDIO_SCALE_B)).astype(np.float32)
+
+
 def make_inputs(batch: int, seed: int = INPUT_SEED) -> Tuple[np.ndarray, np.ndarray]:
     """Synthetic frames: x ~ U(0,1) [B,6,160,160], audio ~ N(0,1) [B,32,32,32].
 

@@ -22,6 +22,18 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_b():
+    """Second reference fixture (recipe G1.2-B: gammas of both signs, small BatchNorm variances, audio x4, B=3)."""
+    return np.load(os.path.join(GOLDEN, "unet_g12b_b3.npz"))
+
+
+@pytest.fixture(scope="session")
+def recipe_sd_b():
+    from calipsync_amd import recipe
+    return recipe.make_state_dict_b()
+
+
+@pytest.fixture(scope="session")
 def recipe_sd():
     from calipsync_amd import recipe
     return recipe.make_state_dict()

@@ -1,6 +1,7 @@
 """Generate the golden fixtures by running the REFERENCE itself (build container only).
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py        # G1.2,   B=2 -> unet_g12_b2.npz
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py b      # G1.2-B, B=3 -> unet_g12b_b3.npz
 
 Imports ``/root/reference/module/unet.py`` (read-only mount; it needs only
 ``torch``), loads the repo's deterministic "G1.2" state_dict
@@ -53,15 +54,16 @@ def summarize(name: str, t: torch.Tensor, store: dict, full: bool) -> None:
         store[f"{name}.samples"] = flat[sample_indices(flat.size)]
 
 
-def main() -> None:
+def main(variant: str = "") -> None:
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    sd_np = recipe.make_state_dict()
+    sd_np = recipe.make_state_dict_b() if variant == "b" else recipe.make_state_dict()
     net = Model(6, "hubert").eval()
     missing = net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}, strict=True)
     print("load_state_dict:", missing)
 
-    x_np, a_np = recipe.make_inputs(BATCH)
+    x_np, a_np = recipe.make_inputs_b() if variant == "b" else recipe.make_inputs(BATCH)
+    batch = x_np.shape[0]
     x, a = torch.from_numpy(x_np), torch.from_numpy(a_np)
 
     taps: dict = {}
@@ -121,15 +123,16 @@ def main() -> None:
     store["weights_sha256"] = np.frombuffer(h.digest(), dtype=np.uint8)
     store["inputs_sha256"] = np.frombuffer(
         hashlib.sha256(x_np.tobytes() + a_np.tobytes()).digest(), dtype=np.uint8)
-    store["batch"] = np.array([BATCH])
-    np.savez(os.path.join(HERE, "unet_g12_b2.npz"), **store)
+    store["batch"] = np.array([batch])
+    path = os.path.join(HERE, "unet_g12b_b3.npz" if variant == "b" else "unet_g12_b2.npz")
+    np.savez(path, **store)
 
-    with open(os.path.join(HERE, "state_dict_manifest.txt"), "w") as f:
-        for k, v in net.state_dict().items():
-            f.write(f"{k} {tuple(v.shape)} {str(v.dtype).replace('torch.', '')}\n")
-    print("wrote", os.path.join(HERE, "unet_g12_b2.npz"),
-          os.path.getsize(os.path.join(HERE, "unet_g12_b2.npz")) // 1024, "KiB")
+    if not variant:
+        with open(os.path.join(HERE, "state_dict_manifest.txt"), "w") as f:
+            for k, v in net.state_dict().items():
+                f.write(f"{k} {tuple(v.shape)} {str(v.dtype).replace('torch.', '')}\n")
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else "")

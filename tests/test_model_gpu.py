@@ -51,6 +51,38 @@ def test_golden_intermediates(net, golden, name):
     assert d < 2e-5, (name, d)
 
 
+@pytest.fixture(scope="module")
+def net_b(recipe_sd_b):
+    m = Model(6, "hubert").to("cuda:0")
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe_sd_b.items()})
+    return m.eval()
+
+
+def test_golden_b_output(net_b, golden_b):
+    """Second reference fixture: gammas of both signs, BatchNorm channels with running_var = 1e-3 (the float64
+    fold in pack.py must not lose them), audio x4, B = 3."""
+    x, a = recipe.make_inputs_b()
+    out = net_b(torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda())
+    assert out.shape == (3, 3, 160, 160)
+    d = np.abs(out.cpu().numpy() - golden_b["out.full"]).max()
+    print("max|d| vs reference golden B:", d)
+    assert d < TOL and d < EXPECT
+
+
+@pytest.mark.parametrize("name", TAPS)
+def test_golden_b_intermediates(net_b, golden_b, name):
+    x, a = recipe.make_inputs_b()
+    net_b(torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda())
+    t = net_b.tap(name, 3).cpu().numpy()
+    assert tuple(golden_b[f"{name}.shape"]) == t.shape
+    if f"{name}.full" in golden_b:
+        ref, got = golden_b[f"{name}.full"].reshape(-1), t.reshape(-1)
+    else:
+        ref, got = golden_b[f"{name}.samples"], t.reshape(-1)[sample_indices(t.size)]
+    d = np.abs(got - ref).max() / max(1.0, float(np.abs(ref).max()))
+    assert d < 2e-5, (name, d)
+
+
 @pytest.mark.parametrize("batch", [1, 3, 64])
 def test_against_oracle(net, recipe_sd, batch):
     """configs[0]/[1] of BASELINE.json: B=1 plumbing and B=64 fp32 vs the CPU path."""

@@ -51,6 +51,57 @@ def test_intermediates_match_reference(golden, oracle_run, name):
     assert abs((f64 * f64).sum() - s[2]) <= 1e-5 * max(1.0, s[2])
 
 
+@pytest.fixture(scope="module")
+def oracle_run_b(recipe_sd_b):
+    torch.set_num_threads(8)
+    sd = unet_oracle.to_torch(recipe_sd_b)
+    x, a = recipe.make_inputs_b()
+    taps = {}
+    out = unet_oracle.forward(sd, torch.from_numpy(x), torch.from_numpy(a), taps)
+    return out, taps
+
+
+def test_recipe_b_is_bit_reproducible(golden_b, recipe_sd_b):
+    import hashlib
+    from calipsync_amd import arch
+    h = hashlib.sha256()
+    for k, _s, _d, _r in arch.manifest():
+        h.update(np.ascontiguousarray(recipe_sd_b[k]).tobytes())
+    assert bytes(golden_b["weights_sha256"]) == h.digest()
+    x, a = recipe.make_inputs_b()
+    assert x.shape[0] == int(golden_b["batch"][0]) == 3
+    assert bytes(golden_b["inputs_sha256"]) == hashlib.sha256(x.tobytes() + a.tobytes()).digest()
+    # the corners the fixture exists for
+    gam = [float(recipe_sd_b[f"attention_blocks.{i}.cross_attention.gamma"][0]) for i in range(4)]
+    assert min(gam) < 0 < max(gam)
+    var = recipe_sd_b["inc.inconv.0.conv.1.running_var"]
+    assert (var == np.float32(1e-3)).sum() >= 1
+    assert float(np.abs(a).max()) > 12.0
+
+
+def test_output_matches_reference_b(golden_b, oracle_run_b):
+    """Same pin on the second fixture: negative / small / large attention gammas, BatchNorm channels with
+    running_var = 1e-3 (eps matters in the fold), audio four times larger, an odd batch."""
+    out, _ = oracle_run_b
+    ref = golden_b["out.full"]
+    assert out.shape == ref.shape == (3, 3, 160, 160)
+    assert np.abs(out.numpy() - ref).max() <= TOL
+    assert np.abs(out.numpy().astype(np.float64) - golden_b["out64.full"]).max() < 5e-6
+    assert float(golden_b["audio_swap_maxdiff"][0]) > 1e-2
+
+
+@pytest.mark.parametrize("name", TAPS)
+def test_intermediates_match_reference_b(golden_b, oracle_run_b, name):
+    _, taps = oracle_run_b
+    t = taps[name].contiguous().numpy()
+    assert tuple(golden_b[f"{name}.shape"]) == t.shape
+    if f"{name}.full" in golden_b:
+        ref, got = golden_b[f"{name}.full"].reshape(-1), t.reshape(-1)
+    else:
+        ref, got = golden_b[f"{name}.samples"], t.reshape(-1)[sample_indices(t.size)]
+    assert np.abs(got - ref).max() <= TOL * max(1.0, float(np.abs(ref).max()))
+
+
 def _close(got, ref):
     """|d| <= TOL relative to the tensor's magnitude (activations reach ~1e1)."""
     return np.abs(got - ref).max() <= TOL * max(1.0, float(np.abs(ref).max()))

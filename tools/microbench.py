@@ -93,13 +93,18 @@ def bench_gemm(args):
         m = int(round(rows * args.batch))
         if k % (64 if args.dtype == "bf16" else 32):
             continue
-        a = torch.randn(m, k, device=DEV).to(tdt)
-        w = (torch.randn(n, k, device=DEV) / k ** 0.5).to(tdt)
+        # --rotate R: R operand sets used round-robin, so that with R x (A + W + C) > 256 MB every launch finds
+        # its operands in HBM (as inside the network), not in the L2 / Infinity Cache a repeated launch leaves warm
+        sets = [(torch.randn(m, k, device=DEV).to(tdt), (torch.randn(n, k, device=DEV) / k ** 0.5).to(tdt),
+                 torch.empty(m, n, device=DEV, dtype=tdt)) for _ in range(max(1, args.rotate))]
+        a = sets[0][0]
         bias = torch.randn(n, device=DEV)
-        c = torch.empty(m, n, device=DEV, dtype=tdt)
+        turn = [0]
 
         def fn():
-            st = lib.casync_op_pw_gemm(a.data_ptr(), k, w.data_ptr(), bias.data_ptr(), c.data_ptr(), n, m, n, k, 1,
+            a_, w_, c_ = sets[turn[0] % len(sets)]
+            turn[0] += 1
+            st = lib.casync_op_pw_gemm(a_.data_ptr(), k, w_.data_ptr(), bias.data_ptr(), c_.data_ptr(), n, m, n, k, 1,
                                        0, 0, 0, 0, 0, 0, 0, s)
             assert st == 0, lib.casync_last_error()
         ms = time_ms(fn, args.iters)
@@ -137,6 +142,7 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--shape", default="")
+    ap.add_argument("--rotate", type=int, default=1, help="gemm: operand sets used round-robin (cold operands)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     a = ap.parse_args()
     {"ir": bench_ir, "gemm": bench_gemm, "dw": bench_dw}[a.what](a)

@@ -21,12 +21,15 @@ import os
 import re
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_names import short  # noqa: E402
+
 
 def load(d):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(f"{d}/g*/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            name = re.sub(r"\(anonymous namespace\)::|^void |\(.*", "", r["Kernel_Name"]).strip()
+            name = short(r["Kernel_Name"])
             if name.startswith(("at::", "__amd")) or "elementwise" in name:
                 continue
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -15,6 +15,9 @@ import os
 import re
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_names import short  # noqa: E402
+
 
 def per_kernel(d, counter):
     f = max(glob.glob(f"{d}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
@@ -22,7 +25,7 @@ def per_kernel(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
-        name = re.sub(r"\(anonymous namespace\)::|^void |\(.*", "", r["Kernel_Name"]).strip()
+        name = short(r["Kernel_Name"])
         agg[name].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
 
@@ -36,7 +39,7 @@ for k in sorted(set(fetch) | set(write)):
     wk, _ = write.get(k, (0.0, 0))
     out[k] = {"launches_sampled": n, "fetch_bytes_per_launch": round(2 * fk * 1024), "write_bytes_per_launch": round(wk * 1024),
               "hbm_bytes_per_launch": round((2 * fk + wk) * 1024)}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of bench.py B=64 fp32, "
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of bench.py " + (sys.argv[4] if len(sys.argv) > 4 else "B=64 fp32") + ", "
                      "--replay-only (the timed run's launches, serialised); FETCH_SIZE x2 (gfx950), KB -> bytes",
            "kernels": out}, open(sys.argv[3], "w"), indent=1)
 for k, v in out.items():
