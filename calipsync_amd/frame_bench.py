@@ -35,18 +35,39 @@ def run(net, dev, batch: int = 64, batches: int = 8, warmup: int = 2) -> dict:
     masks = [None] * batch
     feats = torch.from_numpy(np.random.default_rng(1).standard_normal((batch * (batches + warmup) + 16, 2, 1024))
                              .astype(np.float32)).to(dev)
-    t_model = []
-    for k in range(warmup + batches):
-        if k == warmup:
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-        idx = list(range(k * batch, (k + 1) * batch))
-        out = frame_loop.process_batch_device(net, imgs, lms, masks, features=feats, frame_indices=idx)
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
+    def timed(pipelined: bool) -> float:
+        prev = None
+        n_out = 0
+        for k in range(warmup + batches):
+            if k == warmup:
+                if prev is not None:
+                    n_out += len(prev.result())
+                    prev = None
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                n_out = 0
+            idx = list(range(k * batch, (k + 1) * batch))
+            cur = frame_loop.submit_batch_device(net, imgs, lms, masks, features=feats, frame_indices=idx)
+            if pipelined:          # FrameSynthesizer.iterate_synthesized_frames: one batch in flight
+                if prev is not None:
+                    n_out += len(prev.result())
+                prev = cur
+            else:                  # process_batch: submit and wait, batch by batch
+                n_out += len(cur.result())
+        if prev is not None:
+            n_out += len(prev.result())
+        torch.cuda.synchronize(dev)
+        assert n_out == batch * batches, n_out
+        return time.perf_counter() - t0
+
+    dt_seq, dt_pipe = timed(False), timed(True)
     side = int(np.mean([int(l[31][0]) - int(l[1][0]) for l in lms]))
-    return {"frames_per_s": round(batch * batches / dt, 1), "ms_per_batch": round(1e3 * dt / batches, 2), "batch": batch,
+    return {"frames_per_s": round(batch * batches / dt_pipe, 1), "ms_per_batch": round(1e3 * dt_pipe / batches, 2),
+            "frames_per_s_batch_by_batch": round(batch * batches / dt_seq, 1),
+            "ms_per_batch_batch_by_batch": round(1e3 * dt_seq / batches, 2), "batch": batch,
             "frame": "1920x1080 BGR uint8, synthetic", "mean_crop_side_px": side,
-            "pipeline": "host crop-box slice -> 1 H2D -> resize168 -> forward_windows -> uint8 -> resize back -> "
-                        "fillPoly -> dilate -> blend -> 1 D2H -> host paste (calipsync_amd.frame_loop.process_batch_device)",
-            "frames_out": len(out)}
+            "pipeline": "host crop-box slices into one pinned buffer -> 1 H2D -> resize168 -> forward_windows -> uint8 -> "
+                        "resize back -> fillPoly -> dilate -> blend -> 1 D2H (pinned) -> paste into threaded frame copies "
+                        "(calipsync_amd.frame_loop.submit_batch_device / PendingBatch.result); frames_per_s = one batch "
+                        "in flight as FrameSynthesizer.iterate_synthesized_frames runs it, batch_by_batch = process_batch",
+            "frames_out": batch * batches}

@@ -8,6 +8,8 @@ one launch per batch, bit-exactly; ``cv2.resize`` and the polygon blend keep the
 (their fixed-point arithmetic cannot be pinned without cv2)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -99,6 +101,64 @@ def crop_box(lms, height: int, img_width: int):
     return ymin, ymax, xmin, xmax, width
 
 
+_POOL = None
+
+
+def _host_pool():
+    global _POOL
+    if _POOL is None:
+        import concurrent.futures
+        n = min(8, max(2, (os.cpu_count() or 2) // 2))
+        try:
+            n = min(n, max(2, len(os.sched_getaffinity(0))))
+        except AttributeError:
+            pass
+        _POOL = concurrent.futures.ThreadPoolExecutor(max_workers=n, thread_name_prefix="casync-frames")
+    return _POOL
+
+
+class PendingBatch:
+    """A batch whose GPU work, frame copies and download are in flight (``submit_batch_device``); ``result()``
+    waits for them and pastes the blended regions into the copied frames."""
+
+    def __init__(self, copies, boxes, geom, host, done, keep):
+        self._copies, self._boxes, self._geom, self._host, self._done, self._keep = copies, boxes, geom, host, done, keep
+        self._frames = None
+
+    def result(self):
+        if self._frames is None:
+            self._done.synchronize()
+            host = self._host.numpy()
+            frames = []
+            for i, fut in enumerate(self._copies):
+                out = fut.result()
+                if self._geom[i, 4]:
+                    ymin, ymax, xmin, xmax, _ = self._boxes[i]
+                    h, w = ymax - ymin, xmax - xmin
+                    out[ymin:ymax, xmin:xmax] = host[self._geom[i, 0]:self._geom[i, 0] + h * w * 3].reshape(h, w, 3)
+                frames.append(out)
+            _release_pinned(self._host)
+            if self._keep is not None:
+                _release_pinned(self._keep)
+            self._frames, self._host, self._keep = frames, None, None
+        return self._frames
+
+
+_PINNED = {}   # bytes (rounded up to 1 MiB) -> free pinned uint8 host buffers
+
+
+def _acquire_pinned(nbytes: int) -> torch.Tensor:
+    size = max(1, (nbytes + (1 << 20) - 1) >> 20) << 20
+    free = _PINNED.setdefault(size, [])
+    return free.pop() if free else torch.empty(size, dtype=torch.uint8).pin_memory()
+
+
+def _release_pinned(buf: torch.Tensor) -> None:
+    free = _PINNED.setdefault(buf.numel(), [])
+    if len(free) < 4:
+        free.append(buf)
+
+
 def process_batch_device(net, batch_images, batch_landmarks, batch_masks, *, windows=None, features=None,
                          frame_indices=None):
     """``FrameSynthesizer.process_batch`` with everything between the crop box and the pasted-back frame on the
@@ -108,13 +168,23 @@ def process_batch_device(net, batch_images, batch_landmarks, batch_masks, *, win
     ``windows``: device tensor [B,32,32,32] (host-built HuBERT windows, the reference's own calling form), or
     ``features`` [T,2,1024] on the device + ``frame_indices`` (windows gathered on the device).
     Returns the list of synthesised frames (copies; the inputs are not modified, like infer_api.py:201)."""
+    return submit_batch_device(net, batch_images, batch_landmarks, batch_masks, windows=windows, features=features,
+                               frame_indices=frame_indices).result()
+
+
+def submit_batch_device(net, batch_images, batch_landmarks, batch_masks, *, windows=None, features=None,
+                        frame_indices=None) -> PendingBatch:
+    """The asynchronous half of ``process_batch_device``: host geometry, upload, every launch and the download
+    are enqueued, the per-frame copies run on the host pool; nothing here waits for the GPU.  A caller that
+    submits batch k+1 before taking ``result()`` of batch k overlaps its host work with the GPU."""
     lib = _lib.load()
     dev = net._device()
     if dev.type != "cuda":
         raise RuntimeError("process_batch_device needs the model on a ROCm device (no CPU fallback)")
     B = len(batch_images)
     if B == 0:
-        return []
+        done = torch.cuda.Event()
+        return PendingBatch([], [], np.zeros((0, GEOM_WORDS), dtype=np.int32), _acquire_pinned(1), done, None)
     geom = np.zeros((B, GEOM_WORDS), dtype=np.int32)
     pts = np.zeros((B, 33, 2), dtype=np.int32)
     boxes, regions, fmasks = [], [], []
@@ -127,7 +197,7 @@ def process_batch_device(net, batch_images, batch_landmarks, batch_masks, *, win
         if h <= 0 or w <= 0 or width <= 0:
             raise ValueError(f"frame {i}: empty crop box {(ymin, ymax, xmin, xmax)} (cv2.resize would fail)")
         boxes.append((ymin, ymax, xmin, xmax, width))
-        regions.append(np.ascontiguousarray(img[ymin:ymax, xmin:xmax]).reshape(-1))
+        regions.append(img[ymin:ymax, xmin:xmax])
         fp = np.asarray(lms[:33], dtype=np.float64).copy()          # infer_api.py:281-289
         fp[:, 0] -= xmin
         fp[:, 1] -= ymin
@@ -153,14 +223,35 @@ def process_batch_device(net, batch_images, batch_landmarks, batch_masks, *, win
     max_h, max_w = int(geom[:, 1].max()), int(geom[:, 2].max())
     max_width = int((geom[:, 3] * geom[:, 4]).max())
     stream = _stream(dev)
+    # The reference returns NEW frames (frame = img.copy(), infer_api.py:201).  64 copies of a 1080p frame are
+    # ~30 ms on one core, four times the GPU work of the batch, so they run on a small thread pool (NumPy copies
+    # release the GIL) while the GPU is busy, and only the paste waits for them.
+    copies = [_host_pool().submit(np.copy, img) for img in batch_images]
+    # ONE pinned staging buffer, ONE upload: [crop regions | geom | pts | face masks], 16-B aligned parts
+    al = lambda n: (n + 15) & ~15
+    o_geom = al(reg_off)
+    o_pts = o_geom + al(geom.nbytes)
+    o_fm = o_pts + al(pts.nbytes)
+    total = o_fm + 4 * fmask_off
+    stage = _acquire_pinned(total)
+    st = stage.numpy()
+    off = 0
+    for r in regions:
+        n = r.shape[0] * r.shape[1] * 3
+        st[off:off + n].reshape(r.shape)[...] = r
+        off += n
+    st[o_geom:o_geom + geom.nbytes] = geom.reshape(-1).view(np.uint8)
+    st[o_pts:o_pts + pts.nbytes] = pts.reshape(-1).view(np.uint8)
+    if fmasks:
+        st[o_fm:total] = np.concatenate(fmasks).view(np.uint8)
     with torch.cuda.device(dev):
-        up = lambda a: torch.from_numpy(a).to(dev, non_blocking=False)
-        regions_dev = up(np.concatenate(regions))
-        geom_dev, pts_dev = up(geom.reshape(-1)), up(pts.reshape(-1))
-        fmasks_dev = up(np.concatenate(fmasks)) if fmasks else None
+        staged = torch.empty(total, dtype=torch.uint8, device=dev)
+        staged.copy_(stage[:total], non_blocking=True)
+        base = staged.data_ptr()
+        p_regions, p_geom, p_pts, p_fm = base, base + o_geom, base + o_pts, (base + o_fm if fmasks else 0)
         crops = torch.empty((B, 168, 168, 3), dtype=torch.uint8, device=dev)
         x = torch.empty((B, 6, 160, 160), dtype=torch.float32, device=dev)
-        _lib.check(lib.casync_frame_prepare(regions_dev.data_ptr(), geom_dev.data_ptr(), B, crops.data_ptr(), x.data_ptr(),
+        _lib.check(lib.casync_frame_prepare(p_regions, p_geom, B, crops.data_ptr(), x.data_ptr(),
                                             stream), "casync_frame_prepare")
         if windows is not None:
             pred = net(x, windows)
@@ -172,17 +263,13 @@ def process_batch_device(net, batch_images, batch_landmarks, batch_masks, *, win
         area = torch.empty(B, dtype=torch.int32, device=dev)
         out_regions = torch.empty(reg_off, dtype=torch.uint8, device=dev)
         _lib.check(lib.casync_frame_paste_back(
-            regions_dev.data_ptr(), geom_dev.data_ptr(), pts_dev.data_ptr(),
-            fmasks_dev.data_ptr() if fmasks_dev is not None else 0, crops.data_ptr(), pred.data_ptr(), B, max_h, max_w,
+            p_regions, p_geom, p_pts, p_fm, crops.data_ptr(), pred.data_ptr(), B, max_h, max_w,
             max_width, mask_off, synth.data_ptr(), mask_a.data_ptr(), mask_b.data_ptr(), area.data_ptr(),
             out_regions.data_ptr(), stream), "casync_frame_paste_back")
-        host = out_regions.cpu().numpy()                    # the ONE download of the batch
-    results = []
-    for i, img in enumerate(batch_images):
-        out = img.copy()
-        if geom[i, 4]:
-            ymin, ymax, xmin, xmax, _ = boxes[i]
-            h, w = ymax - ymin, xmax - xmin
-            out[ymin:ymax, xmin:xmax] = host[geom[i, 0]:geom[i, 0] + h * w * 3].reshape(h, w, 3)
-        results.append(out)
-    return results
+        host = _acquire_pinned(reg_off)                      # the ONE download of the batch, into pinned memory
+        host[:reg_off].copy_(out_regions, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
+    # device tensors may be dropped here (torch's allocator is stream-ordered on the current stream); the two
+    # pinned buffers are ours until the event has passed, i.e. until result()
+    return PendingBatch(copies, boxes, geom, host, done, stage)

@@ -156,13 +156,25 @@ class FrameSynthesizer:
             print(f"process_batch failed, returning the original frames: {exc!r}")
             return batch_images
 
-    def _process_batch_indices(self, batch_images, batch_landmarks, batch_masks, features_dev, indices) -> list:
+    def _submit_batch_indices(self, batch_images, batch_landmarks, batch_masks, features_dev, indices):
+        """Enqueue a batch (frame_loop.submit_batch_device); a failure keeps the reference's contract of handing
+        back the originals (infer_api.py:352-357) when the batch is collected."""
         try:
-            return frame_loop.process_batch_device(self.net, batch_images, batch_landmarks, batch_masks,
-                                                   features=features_dev, frame_indices=indices)
+            return frame_loop.submit_batch_device(self.net, batch_images, batch_landmarks, batch_masks,
+                                                  features=features_dev, frame_indices=indices), batch_images
         except Exception as exc:
             print(f"process_batch failed, returning the original frames: {exc!r}")
-            return batch_images
+            return None, batch_images
+
+    @staticmethod
+    def _collect(pending, originals) -> list:
+        if pending is None:
+            return originals
+        try:
+            return pending.result()
+        except Exception as exc:
+            print(f"process_batch failed, returning the original frames: {exc!r}")
+            return originals
 
     # ------------------------------------------------------------------ the loop (infer_api.py:359-451)
     def iterate_synthesized_frames(self, features: np.ndarray, start_frame_idx: int = 0,
@@ -171,6 +183,7 @@ class FrameSynthesizer:
         time_stats = {"load_frame": 0.0, "get_audio": 0.0, "process_batch": 0.0}
         total_frames = len(features)
         features_dev = None
+        in_flight: list = []
         try:
             if is_generate_sync_frame and total_frames:
                 t0 = time.time()   # one upload of the whole [T,2,1024] array replaces B x 128 KB per batch
@@ -189,17 +202,21 @@ class FrameSynthesizer:
                             yield {"frame": original_image, "index": self.last_logical_index,
                                    "physical_index": frame_sequence[i]}
                         continue
+                    # one batch in flight: batch k+1 is loaded, cropped and enqueued while the GPU works on
+                    # batch k, whose frames are yielded afterwards -- same frames, same order
                     t0 = time.time()
-                    processed = self._process_batch_indices(batch_images, batch_landmarks, batch_masks, features_dev,
-                                                            list(range(batch_start, batch_end)))
+                    pending, originals = self._submit_batch_indices(batch_images, batch_landmarks, batch_masks,
+                                                                    features_dev, list(range(batch_start, batch_end)))
+                    in_flight.append((pending, originals, frame_sequence))
                     time_stats["process_batch"] += time.time() - t0
-                    for i, frame in enumerate(processed):
-                        self.last_logical_index += 1
-                        yield {"frame": frame, "index": self.last_logical_index, "physical_index": frame_sequence[i]}
+                    if len(in_flight) > 1:
+                        yield from self._drain_one(in_flight, time_stats)
                 except Exception as exc:        # a failed batch is skipped, the iterator goes on (:429-436)
                     print(f"batch starting at {batch_start} failed: {exc!r}")
                     time.sleep(0.1)
                     continue
+            while in_flight:
+                yield from self._drain_one(in_flight, time_stats)
         except Exception as exc:                # fatal: one black frame so the consumer does not hang (:438-446)
             print(f"frame iterator failed: {exc!r}")
             self.last_logical_index += 1
@@ -211,6 +228,15 @@ class FrameSynthesizer:
                 print(f"average frame rate: {total_frames / total_time:.2f} FPS "
                       f"(load {time_stats['load_frame']:.2f} s, audio {time_stats['get_audio']:.2f} s, "
                       f"batches {time_stats['process_batch']:.2f} s)")
+
+    def _drain_one(self, in_flight: list, time_stats: dict):
+        pending, originals, frame_sequence = in_flight.pop(0)
+        t0 = time.time()
+        processed = self._collect(pending, originals)
+        time_stats["process_batch"] += time.time() - t0
+        for i, frame in enumerate(processed):
+            self.last_logical_index += 1
+            yield {"frame": frame, "index": self.last_logical_index, "physical_index": frame_sequence[i]}
 
     def __del__(self):
         if hasattr(self, "executor"):
