@@ -60,7 +60,10 @@ def run(net, dev, batch: int = 64, batches: int = 8, warmup: int = 2) -> dict:
         assert n_out == batch * batches, n_out
         return time.perf_counter() - t0
 
-    dt_seq, dt_pipe = timed(False), timed(True)
+    # host-bound (frame copies, slicing): alternate the two modes three times and keep each mode's best
+    dt_seq, dt_pipe = min(timed(False) for _ in range(1)), min(timed(True) for _ in range(1))
+    for _ in range(2):
+        dt_seq, dt_pipe = min(dt_seq, timed(False)), min(dt_pipe, timed(True))
     side = int(np.mean([int(l[31][0]) - int(l[1][0]) for l in lms]))
     return {"frames_per_s": round(batch * batches / dt_pipe, 1), "ms_per_batch": round(1e3 * dt_pipe / batches, 2),
             "frames_per_s_batch_by_batch": round(batch * batches / dt_seq, 1),
@@ -70,4 +73,4 @@ def run(net, dev, batch: int = 64, batches: int = 8, warmup: int = 2) -> dict:
                         "resize back -> fillPoly -> dilate -> blend -> 1 D2H (pinned) -> paste into threaded frame copies "
                         "(calipsync_amd.frame_loop.submit_batch_device / PendingBatch.result); frames_per_s = one batch "
                         "in flight as FrameSynthesizer.iterate_synthesized_frames runs it, batch_by_batch = process_batch",
-            "frames_out": batch * batches}
+            "frames_out": batch * batches, "repeats": "best of 3 alternating runs of 8 batches"}

@@ -14,6 +14,27 @@ from frame_data import make_frames, write_dataset
 from oracle import frame_loop_oracle, frame_ops_oracle as fo
 
 
+# ------------------------------------------------------------------ the pin a maintainer WITH cv2 can run
+def test_oracle_against_cv2():
+    """Not runnable in this image (no cv2): compares every restated OpenCV call with the real one on random data.
+    Until it has run somewhere, the cv2 half of rows f1 is "parity unpinned"."""
+    cv2 = pytest.importorskip("cv2")
+    rng = np.random.default_rng(5)
+    for (h, w) in [(211, 190), (384, 384), (97, 300), (168, 168), (336, 336), (84, 84)]:
+        src = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(fo.resize_linear_u8(src, (168, 168)), cv2.resize(src, (168, 168)))
+        small = rng.integers(0, 256, (160, 160, 3), dtype=np.uint8)
+        assert np.array_equal(fo.resize_linear_u8(small, (w, w)), cv2.resize(small, (w, w)))
+        m = rng.random((64, 48)).astype(np.float32)
+        assert np.array_equal(fo.resize_linear_f32(m, (w, h)), cv2.resize(m, (w, h)))
+        pts = rng.integers(-20, max(h, w) + 20, (33, 2)).astype(np.int32)
+        want = np.zeros((h, w), np.uint8)
+        cv2.fillPoly(want, [pts], 255)
+        assert np.array_equal(fo.fill_poly((h, w), pts), want)
+        e = int(rng.integers(1, 40))
+        assert np.array_equal(fo.dilate_square(want, e), cv2.dilate(want, np.ones((2 * e + 1, 2 * e + 1), np.uint8), iterations=1))
+
+
 # ------------------------------------------------------------------ oracle properties (CPU)
 def test_resize_u8_basic_properties():
     rng = np.random.default_rng(0)

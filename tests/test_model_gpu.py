@@ -189,11 +189,15 @@ def test_bf16_engine_error_is_reported_not_hidden(net_bf16, golden):
     assert out.dtype == torch.float32 and out.shape == (2, 3, 160, 160)
     d = np.abs(out.cpu().numpy() - golden["out.full"])
     print(f"bf16 engine vs reference golden: max {d.max():.3e} mean {d.mean():.3e}")
-    assert d.max() < 4e-2 and d.mean() < 4e-3
+    assert d.max() < 1.1e-2 and d.mean() < 1.3e-3      # measured 8.7e-3 / 1.03e-3 (+25 %)
     assert d.max() > 1e-4          # it really is the bf16 path
 
 
-@pytest.mark.parametrize("name", ["x1", "x5", "a", "tx", "kx", "fuse", "u4"])
+# measured max relative error per tap (round 2) + 25 %
+BF16_TAP_BARS = {"x1": 3.0e-3, "x5": 8.0e-3, "a": 9.6e-3, "tx": 5.5e-3, "kx": 9.8e-3, "fuse": 9.4e-3, "u4": 1.1e-2}
+
+
+@pytest.mark.parametrize("name", sorted(BF16_TAP_BARS))
 def test_bf16_intermediates_track_fp32(net_bf16, golden, name):
     x, a = recipe.make_inputs(2)
     net_bf16(torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda())
@@ -204,7 +208,7 @@ def test_bf16_intermediates_track_fp32(net_bf16, golden, name):
         ref, got = golden[f"{name}.samples"], t.reshape(-1)[sample_indices(t.size)]
     rel = np.abs(got - ref).max() / max(1.0, float(np.abs(ref).max()))
     print(f"bf16 {name}: max rel err {rel:.3e}")
-    assert rel < 6e-2
+    assert rel < BF16_TAP_BARS[name]
 
 
 def test_bf16_frames_independent(net_bf16):
