@@ -61,22 +61,32 @@ template <> struct MfmaK<bf16_t> {
 // Epilogue rows shared by both GEMM kernels: the fp32 C tile staged row-major in LDS ->
 // bias, scaled pre-residual, LReLU, post-residual, second affine + LReLU, running-sum output,
 // with one 16-B global access per thread and tensor (4 fp32 or 8 bf16 columns), rows coalesced.
-template <typename T, int NT, int BM, int BN>
-__device__ __forceinline__ void epilogue_rows(const float* Cs, int m0, int n0, int M, T* __restrict__ C,
-                                              int ldc, const GemmEpilogue& epi, int tid) {
-  constexpr int CPT = V16<T>::N, TPR = BN / CPT, RPP = NT / TPR, LDC_S = BN + 4;
+// The per-column constants of the epilogue for the CPT columns a thread owns (loaded once per output tile).
+template <typename T>
+struct EpiCols {
+  static constexpr int CPT = V16<T>::N;
+  float bias[CPT], pscale[CPT], as[CPT], at[CPT];
+  __device__ __forceinline__ void load(const GemmEpilogue& epi, int n) {
+#pragma unroll
+    for (int e = 0; e < CPT; e += 4) {
+      const f32x4 b = epi.bias ? *reinterpret_cast<const f32x4*>(epi.bias + n + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 p = epi.pre_scale ? *reinterpret_cast<const f32x4*>(epi.pre_scale + n + e) : f32x4{1.f, 1.f, 1.f, 1.f};
+      const f32x4 s = epi.aff_s ? *reinterpret_cast<const f32x4*>(epi.aff_s + n + e) : f32x4{1.f, 1.f, 1.f, 1.f};
+      const f32x4 t = epi.aff_s ? *reinterpret_cast<const f32x4*>(epi.aff_t + n + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bias[e + q] = b[q], pscale[e + q] = p[q], as[e + q] = s[q], at[e + q] = t[q];
+    }
+  }
+};
+
+// PAD: floats of padding per staged row; SWZ: the staging tile has no padding and column bit 5 is flipped on rows
+// with bit 2 set instead (the wide kernel's 32-row slabs: the two lane halves of an MFMA C register are 4 rows apart).
+template <typename T, int NT, int BM, int BN, int PAD = 4, bool SWZ = false>
+__device__ __forceinline__ void epilogue_rows_cols(const float* Cs, int m0, int n0, int M, T* __restrict__ C, int ldc,
+                                                   const GemmEpilogue& epi, int tid, const EpiCols<T>& k) {
+  constexpr int CPT = V16<T>::N, TPR = BN / CPT, RPP = NT / TPR, LDC_S = BN + PAD;
   static_assert(BN % CPT == 0 && NT % TPR == 0 && BM % RPP == 0, "epilogue thread map");
   const int c0 = (tid % TPR) * CPT, rr = tid / TPR, n = n0 + c0;
-  float bias[CPT], pscale[CPT], as[CPT], at[CPT];
-#pragma unroll
-  for (int e = 0; e < CPT; e += 4) {
-    const f32x4 b = epi.bias ? *reinterpret_cast<const f32x4*>(epi.bias + n + e) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 p = epi.pre_scale ? *reinterpret_cast<const f32x4*>(epi.pre_scale + n + e) : f32x4{1.f, 1.f, 1.f, 1.f};
-    const f32x4 s = epi.aff_s ? *reinterpret_cast<const f32x4*>(epi.aff_s + n + e) : f32x4{1.f, 1.f, 1.f, 1.f};
-    const f32x4 t = epi.aff_s ? *reinterpret_cast<const f32x4*>(epi.aff_t + n + e) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bias[e + q] = b[q], pscale[e + q] = p[q], as[e + q] = s[q], at[e + q] = t[q];
-  }
 #pragma unroll 4
   for (int p = 0; p < BM / RPP; ++p) {
     const int row = rr + RPP * p, m = m0 + row;
@@ -84,14 +94,14 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, int m0, int n0, i
     V16<T> v;
 #pragma unroll
     for (int e = 0; e < CPT; e += 4) {
-      const f32x4 c = *reinterpret_cast<const f32x4*>(Cs + row * LDC_S + c0 + e);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(Cs + row * LDC_S + ((c0 + e) ^ (SWZ ? ((row >> 2) & 1) << 5 : 0)));
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v.v[e + q] = c[q] + bias[e + q];
+      for (int q = 0; q < 4; ++q) v.v[e + q] = c[q] + k.bias[e + q];
     }
     if (epi.pre_res) {
       const V16<T> r = ld16(static_cast<const T*>(epi.pre_res) + (size_t)m * epi.ld_pre + n);
 #pragma unroll
-      for (int e = 0; e < CPT; ++e) v.v[e] += pscale[e] * r.v[e];
+      for (int e = 0; e < CPT; ++e) v.v[e] += k.pscale[e] * r.v[e];
     }
     if (epi.act) {
 #pragma unroll
@@ -104,7 +114,7 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, int m0, int n0, i
     }
     if (epi.aff_s && !epi.aff_on_acc) {
 #pragma unroll
-      for (int e = 0; e < CPT; ++e) v.v[e] = lrelu(v.v[e] * as[e] + at[e]);
+      for (int e = 0; e < CPT; ++e) v.v[e] = lrelu(v.v[e] * k.as[e] + k.at[e]);
     }
     st16(C + (size_t)m * ldc + n, v);
     if (epi.acc_out) {
@@ -113,11 +123,19 @@ __device__ __forceinline__ void epilogue_rows(const float* Cs, int m0, int n0, i
       for (int e = 0; e < CPT; ++e) sacc.v[e] += v.v[e];
       if (epi.aff_s && epi.aff_on_acc) {
 #pragma unroll
-        for (int e = 0; e < CPT; ++e) sacc.v[e] = lrelu(sacc.v[e] * as[e] + at[e]);
+        for (int e = 0; e < CPT; ++e) sacc.v[e] = lrelu(sacc.v[e] * k.as[e] + k.at[e]);
       }
       st16(static_cast<T*>(epi.acc_out) + (size_t)m * epi.ld_acc + n, sacc);
     }
   }
+}
+
+template <typename T, int NT, int BM, int BN, int PAD = 4, bool SWZ = false>
+__device__ __forceinline__ void epilogue_rows(const float* Cs, int m0, int n0, int M, T* __restrict__ C,
+                                              int ldc, const GemmEpilogue& epi, int tid) {
+  EpiCols<T> k;
+  k.load(epi, n0 + (tid % (BN / V16<T>::N)) * V16<T>::N);
+  epilogue_rows_cols<T, NT, BM, BN, PAD, SWZ>(Cs, m0, n0, M, C, ldc, epi, tid, k);
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -768,6 +786,267 @@ int launch_glds_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, 
   return CASYNC_OK;
 }
 
+// =====================================================================================
+// Wide persistent ring kernel for the bf16 plan's large GEMMs (M = 256 frames x pixels per lane, K = 256..2048).
+// A bf16 k-tile is only 512 MFMA cycles per wave, an output tile of those shapes has 4-16 k-tiles, and a
+// (25600, 1024, 512) GEMM needs 12.5 us of HBM time and 10.7 us of MFMA time -- but took 55 us with 128x128
+// tiles: each tile paid its own first-load latency and its own epilogue (one workgroup per CU, nothing to hide
+// them behind), and 128x128 tiles pull 420 MB through L2 for 79 MB of operands.  This kernel
+//   * takes 256x128 tiles (315 MB through L2), eight waves of 64x64, one workgroup per CU, grid = 256;
+//   * keeps ONE LDS-DMA ring running across all the tiles of a workgroup: the loads of the next tile's first
+//     k-tiles are in flight while the current tile finishes and while its epilogue runs;
+//   * stages the epilogue through 16 KB NEXT TO the ring (32-row slabs), so the ring is never drained.
+// Loads are buffer_load ... lds with per-tile lane offsets and the k position in an SGPR (as in the two-stage
+// loop above).  Synchronisation per k-tile: counted vmcnt (tile `it` landed, `it+1` may be in flight) -> barrier
+// -> issue tile it+2 -> MFMAs.  Around an epilogue the order is: MFMAs of the tile's last k-tile -> vmcnt(0)
+// (only tile it+1 is outstanding) -> epilogue (its stores are now the oldest outstanding operations) -> issue
+// tile it+2; the iteration after it needs no wait, and the one after that waits with the usual count, which by
+// in-order retirement of loads covers the stores and tile it+2 exactly.
+// Requires M % BM == 0, N % BN == 0, K >= 4 k-tiles, operands < 2 GiB.
+// =====================================================================================
+// ds_read_b128 the compiler does not see as an LDS read (no automatic waits: the caller waits on lgkmcnt itself)
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_read16_raw(unsigned lds_addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
+  return v;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NST>
+__global__ __launch_bounds__(64 * WM * WN) void pw_gemm_wide_kernel(const T* __restrict__ A, int lda,
+                                                                    const T* __restrict__ W, T* __restrict__ C, int ldc,
+                                                                    int M, int N, int K, int n_ntiles, int ntiles,
+                                                                    GemmEpilogue epi, int casync_wide_skew) {
+  constexpr int NW = WM * WN, NT = 64 * NW;
+  constexpr int BK = ROWB / (int)sizeof(T);
+  constexpr int ROWS = BM + BN, STAGE = ROWS * ROWB;
+  constexpr int LPT = ROWS / (8 * NW);          // LDS-DMA instructions per wave per k-tile (8 rows each)
+  constexpr int LPA = BM / (8 * NW);            // ... of which the first LPA fetch A rows
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int SLAB = 32;                      // epilogue staging: SLAB x BN floats next to the ring
+  static_assert(ROWS % (8 * NW) == 0 && BM % (8 * NW) == 0, "whole DMA instructions per operand");
+  static_assert(NST == 3, "the wait counts below are written for three stages");
+  static_assert((size_t)NST * STAGE + (size_t)SLAB * BN * 4 <= 160 * 1024, "LDS budget");
+  static_assert(NT / (BN / V16<T>::N) == SLAB, "one epilogue pass per slab");
+  extern __shared__ __attribute__((aligned(16))) char ring[];
+  float* Cs = reinterpret_cast<float*>(ring + (size_t)NST * STAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int r32 = lane & 31, kh = lane >> 5;
+  const int lrow8 = lane >> 3, lcol = lane & 7;
+  const int nk = K / BK;
+  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int IT = my_tiles * nk;
+
+  auto tile_origin = [&](int tile, int& m0, int& n0) __attribute__((always_inline)) {   // XCD-aware bijection tile -> (m0, n0)
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = tile & 7, idx = tile >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int mt = bid / n_ntiles;
+    m0 = mt * BM;
+    n0 = (bid - mt * n_ntiles) * BN;
+  };
+
+  // ---- load stream: k-tiles of this workgroup's tiles, in order, NST-1 ahead of the MFMAs ----
+  int voff[LPT];
+  int ld_k = 0, ld_ti = 0;
+  auto set_voff = [&](int tile) __attribute__((always_inline)) {
+    int m0l, n0l;
+    tile_origin(tile, m0l, n0l);
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) {
+      const int r = (j * NW + wave) * 8 + lrow8;   // row inside the stage: [0,BM) = A, [BM,ROWS) = W
+      const int cs = lcol ^ ((r >> 1) & 7);        // swizzled source column
+      voff[j] = j < LPA ? (int)(((long long)(m0l + r) * lda) * (int)sizeof(T)) + cs * 16
+                        : (int)(((long long)(n0l + r - BM) * K) * (int)sizeof(T)) + cs * 16;
+    }
+  };
+  // k-skew: workgroup w starts every tile's k loop at k-tile (w / 8) % nk and wraps (a sum has no preferred order;
+  // the order is fixed per workgroup, so results repeat bit for bit).  Without it all 32 workgroups of an XCD ask for
+  // the SAME 128-B column of rows 1-2 KB apart at the same time, which lands on a few L2 channels.
+  const int skew = casync_wide_skew ? ((int)blockIdx.x >> 3) % nk : 0;
+  auto issue = [&](int stage) __attribute__((always_inline)) {   // `stage` is wave-uniform: the LDS base goes through M0
+    int kk = ld_k + skew;
+    kk = kk >= nk ? kk - nk : kk;
+    const int soff = kk * ROWB;
+#pragma unroll
+    for (int j = 0; j < LPT; ++j)
+      buffer_load_lds16(j < LPA ? static_cast<const void*>(A) : static_cast<const void*>(W),
+                        j < LPA ? epi.buf_a_bytes : epi.buf_w_bytes,
+                        (void __attribute__((address_space(3)))*)(ring + stage * STAGE + (j * NW + wave_s) * 8 * ROWB), voff[j], soff);
+    if (++ld_k == nk) {
+      ld_k = 0;
+      if (++ld_ti < my_tiles) set_voff((int)blockIdx.x + ld_ti * (int)gridDim.x);
+    }
+  };
+
+  // ---- fragment reads.  The compiler makes every LDS read it knows about wait for ALL outstanding
+  //      `buffer_load ... lds` operations (it cannot tell that they write another ring stage), which would
+  //      drain the ring before every k-tile; so the fragment reads are inline-asm ds_read_b128 with their own
+  //      lgkmcnt waits, tied to the fragment registers so the MFMAs cannot move above them.  LDS byte addresses
+  //      per lane are fixed for the kernel; the stage offset is an immediate (<= 65535: stage 2 has its own bases).
+  unsigned a_adr[2][TM][4], b_adr[2][TN][4];
+  {
+    const unsigned ring_lds = (unsigned)reinterpret_cast<uintptr_t>(ring);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int r = wm * (BM / WM) + i * 32 + r32;
+        a_adr[0][i][g] = ring_lds + r * ROWB + (((2 * g + kh) ^ ((r >> 1) & 7)) << 4);
+        a_adr[1][i][g] = a_adr[0][i][g] + 2 * STAGE;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int r = BM + wn * (BN / WN) + j * 32 + r32;
+        b_adr[0][j][g] = ring_lds + r * ROWB + (((2 * g + kh) ^ ((r >> 1) & 7)) << 4);
+        b_adr[1][j][g] = b_adr[0][j][g] + 2 * STAGE;
+      }
+    }
+  }
+  f32x16 acc[TM][TN];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  static_assert(TM == 2 && TN == 2, "the lgkmcnt waits below are written for 2 + 2 fragments per column pair");
+  auto tile_mma = [&](auto stage_c) __attribute__((always_inline)) {
+    constexpr int S = decltype(stage_c)::value;
+    constexpr int SET = S == 2 ? 1 : 0, OFF = S == 1 ? STAGE : 0;
+    static_assert(OFF <= 65535, "ds_read offset field");
+    f32x4 fa[2][TM], fb[2][TN];
+    auto rd = [&](int g, f32x4 (&xa)[TM], f32x4 (&xb)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) xa[i] = lds_read16_raw<OFF>(a_adr[SET][i][g]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) xb[j] = lds_read16_raw<OFF>(b_adr[SET][j][g]);
+    };
+    // at most N of this wave's LDS reads still outstanding; the fragments pass through the statement
+#define CASYNC_WIDE_WAIT(N, xa, xb) \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xb[0]), "+v"(xb[1]))
+    auto mma = [&](const f32x4 (&xa)[TM], const f32x4 (&xb)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = MfmaK<T>::run(xa[i], xb[j], acc[i][j]);
+    };
+    rd(0, fa[0], fb[0]);
+    rd(1, fa[1], fb[1]);
+    CASYNC_WIDE_WAIT(4, fa[0], fb[0]);
+    mma(fa[0], fb[0]);
+    rd(2, fa[0], fb[0]);
+    CASYNC_WIDE_WAIT(4, fa[1], fb[1]);
+    mma(fa[1], fb[1]);
+    rd(3, fa[1], fb[1]);
+    CASYNC_WIDE_WAIT(4, fa[0], fb[0]);
+    mma(fa[0], fb[0]);
+    CASYNC_WIDE_WAIT(0, fa[1], fb[1]);
+    mma(fa[1], fb[1]);
+#undef CASYNC_WIDE_WAIT
+  };
+
+  // ---- epilogue of the compute tile: 32-row slabs through the staging area next to the ring ----
+  int m0 = 0, n0 = 0;
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    EpiCols<T> cols;                     // per-column constants: once per tile, not once per slab
+    cols.load(epi, n0 + (tid % (BN / V16<T>::N)) * V16<T>::N);
+#pragma unroll
+    for (int sl = 0; sl < BM / SLAB; ++sl) {
+      if (wm == sl / TM) {
+        const int i = sl % TM;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = 4 * kh + (r & 3) + 8 * (r >> 2);                // bit 2 of the row = kh
+            Cs[row * BN + ((wn * (BN / WN) + j * 32 + r32) ^ (kh << 5))] = acc[i][j][r];
+          }
+      }
+      __syncthreads();
+      epilogue_rows_cols<T, NT, SLAB, BN, 0, true>(Cs, m0 + sl * SLAB, n0, M, C, ldc, epi, tid, cols);
+      __syncthreads();
+    }
+  };
+
+  if (my_tiles <= 0) return;
+  // diagnostic stamps (epi.stamps, null in every product call; tools/experiments/gemm_timeline.py): the same slots
+  // as pw_gemm_glds_kernel -- entry, end of k loop / epilogue of the first two tiles, exit, tiles, shader cycles
+  auto stamp = [&](int slot) __attribute__((always_inline)) {
+    if (epi.stamps && tid == 0) epi.stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+  };
+  const unsigned long long cyc0 = epi.stamps ? __builtin_amdgcn_s_memtime() : 0;
+  stamp(0);
+  set_voff((int)blockIdx.x);
+  tile_origin((int)blockIdx.x, m0, n0);
+  zero_acc();
+  issue(0);
+  if (IT > 1) issue(1);
+  int ck = 0, ct = 0, stage = 0, free_stage = 2;   // free_stage: the stage of k-tile it-1 = the one k-tile it+2 goes to
+  bool after_epilogue = false;
+  for (int it = 0; it < IT; ++it) {
+    if (!after_epilogue) {       // (an epilogue has already waited for this k-tile and ended on a barrier)
+      if (it + 1 < IT) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    after_epilogue = false;
+    const bool last_k = ck == nk - 1;
+    if (!last_k && it + 2 < IT) issue(free_stage);
+    // the MFMA part exists once per stage so that the stage offset of every ds_read is an immediate
+    if (stage == 0) tile_mma(std::integral_constant<int, 0>{});
+    else if (stage == 1) tile_mma(std::integral_constant<int, 1>{});
+    else tile_mma(std::integral_constant<int, 2>{});
+    if (last_k) {
+      wait_vmcnt<0>();           // only k-tile it+1 is outstanding; the epilogue's stores become the oldest operations
+      if (ct < 2) stamp(1 + 2 * ct);
+      epilogue();
+      if (ct < 2) stamp(2 + 2 * ct);
+      zero_acc();
+      ck = 0;
+      if (++ct < my_tiles) tile_origin((int)blockIdx.x + ct * (int)gridDim.x, m0, n0);
+      if (it + 2 < IT) issue(free_stage);
+      after_epilogue = true;
+    } else {
+      ++ck;
+    }
+    free_stage = stage;
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+  stamp(5);
+  if (epi.stamps && tid == 0) {
+    epi.stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)my_tiles;
+    epi.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - cyc0;
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NST>
+int launch_wide_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, int k, const GemmEpilogue& epi,
+                  hipStream_t stream) {
+  constexpr size_t lds = (size_t)NST * (BM + BN) * ROWB + (size_t)32 * BN * sizeof(float);
+  static unsigned long long attr_once = 0;
+  auto kern = pw_gemm_wide_kernel<T, BM, BN, WM, WN, NST>;
+  if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)lds)) return st;
+  CASYNC_REQUIRE(m % BM == 0 && n % BN == 0 && k / (ROWB / (int)sizeof(T)) >= 4, "wide gemm: shape m=%d n=%d k=%d", m, n, k);
+  const int n_ntiles = n / BN;
+  const long long ntiles = (long long)(m / BM) * n_ntiles;
+  CASYNC_REQUIRE(ntiles < (1ll << 31), "gemm grid too large");
+  const unsigned long long ab = ((unsigned long long)(m - 1) * lda + k) * sizeof(T), wb = (unsigned long long)n * k * sizeof(T);
+  CASYNC_REQUIRE(ab < (1ull << 31) && wb < (1ull << 31), "gemm: operand larger than 2 GiB");
+  GemmEpilogue e2 = epi;
+  e2.buf_a_bytes = (unsigned)ab;
+  e2.buf_w_bytes = (unsigned)wb;
+  const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds, stream, a, lda, w, c, ldc, m, n, k, n_ntiles, (int)ntiles, e2,
+                     casync_opts().gemm_wide >= 2 ? 1 : 0);
+  CASYNC_CHECK_HIP(hipGetLastError());
+  return CASYNC_OK;
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, int k,
                  const GemmEpilogue& epi, hipStream_t stream) {
@@ -842,11 +1121,16 @@ int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, i
 // Tile choice.  On a 256-CU chip a launch of G workgroups finishes after ceil(G/256) "rounds" of
 // one tile per CU (co-resident tiles share the CU's matrix pipes, so they add, not overlap);
 // pick the tile that minimises rounds x tile area, preferring the larger tile on ties.
-enum Cfg { C128x128 = 0, C128x64, C64x64, C128x32, C64x32, C64x64W2, CFG_COUNT };
+enum Cfg { C128x128 = 0, C128x64, C64x64, C128x32, C64x32, C64x64W2, C256x128, CFG_COUNT };
 
 struct TileCfg { Cfg id; int bm, bn; };
 constexpr TileCfg kTiles[] = {{C128x128, 128, 128}, {C128x64, 128, 64}, {C64x64, 64, 64}, {C128x32, 128, 32},
-                              {C64x32, 64, 32}, {C64x64W2, 64, 64}};
+                              {C64x32, 64, 32}, {C64x64W2, 64, 64}, {C256x128, 256, 128}};
+
+// the wide persistent ring kernel (pw_gemm_wide_kernel): bf16, whole 256x128 tiles, at least one per CU
+bool takes_wide(int m, int n, int k, int dtype) {
+  return dtype == DT_BF16 && m % 256 == 0 && n % 128 == 0 && k / (ROWB / 2) >= 4 && (long long)(m / 256) * (n / 128) >= 256;
+}
 
 // does launch_cfg() send this config to the LDS-DMA ring kernel?
 bool takes_ring(const TileCfg& t, long long tiles, int dtype) {
@@ -859,7 +1143,7 @@ int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullp
   const int forced = casync_opts().gemm_cfg;
   const int nk = k / (ROWB / dtype_size(dtype));
   if (use_sk) *use_sk = false;
-  if (forced >= 0 && forced < CFG_COUNT && n % kTiles[forced].bn == 0) {
+  if (forced == C256x128 ? takes_wide(m, n, k, dtype) : forced >= 0 && forced < CFG_COUNT && n % kTiles[forced].bn == 0) {
     const TileCfg& t = kTiles[forced];
     const long long g = (long long)((m + t.bm - 1) / t.bm) * (n / t.bn);
     if (use_sk) *use_sk = takes_ring(t, g, dtype) && stream_k_split(g, nk, t.bm * t.bn, stream_k).wgs > 0;
@@ -871,6 +1155,7 @@ int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullp
   // +600 is the worse operand reuse of small tiles.  Stream-K makes the last round fractional
   // and adds ~5 us (64x64) to ~10 us (128x64) of short-run start-up, parking and fix-up (priced
   // a little higher here so that it is only chosen where it clearly wins).
+  if (casync_opts().gemm_wide && forced < 0 && takes_wide(m, n, k, dtype)) return C256x128;
   const int conc_mode = casync_opts().gemm_conc, conc_tiles = casync_opts().gemm_conc_tiles;
   const long long t64 = (long long)((m + 63) / 64) * (n / 64);
   int best = -1;
@@ -918,7 +1203,9 @@ const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype, b
   }
   const TileCfg& tc = kTiles[id];
   const long long tiles = (long long)((m + tc.bm - 1) / tc.bm) * (n / tc.bn);
-  if (takes_ring(tc, tiles, dtype))
+  if (id == C256x128)
+    snprintf(buf, sizeof(buf), "pw_gemm_wide_kernel<%s, 256, 128, 4, 2, 3>", t);
+  else if (takes_ring(tc, tiles, dtype))
     snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, %d, false>", t, cfg,
              casync_opts().gemm_pipe != 0 || tc.bm + tc.bn >= 256 ? 3 : 2);
   else
@@ -952,6 +1239,11 @@ int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int 
     case C64x64: return launch_cfg<64, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
     case C64x32: return launch_cfg<64, 32, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
     case C64x64W2: return launch_cfg<64, 64, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
+    case C256x128:
+      if (((size_t)(m - 1) * lda + k) * 2 < (1ull << 31) && (size_t)n * k * 2 < (1ull << 31))
+        return launch_wide_t<bf16_t, 256, 128, 4, 2, 3>(static_cast<const bf16_t*>(a), lda, static_cast<const bf16_t*>(w),
+                                                        static_cast<bf16_t*>(c), ldc, m, n, k, epi, stream);
+      return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
     default: return launch_cfg<128, 32, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
   }
 }

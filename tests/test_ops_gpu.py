@@ -348,6 +348,70 @@ def test_pw_gemm_bf16(bf16_ops, m, n, k):
     assert float(err.max()) < 2 ** -8, float(err.max())
 
 
+@pytest.mark.parametrize("m,n,k", [(65536, 128, 256), (16384, 512, 512), (25600, 1024, 512), (16384, 640, 1024),
+                                   (8192, 1024, 4096)])
+def test_pw_gemm_bf16_wide_kernel(bf16_ops, m, n, k):
+    """The 256x128 persistent ring kernel (bf16 plan, >= 256 tiles): several tiles per workgroup, so the ring
+    runs across tile boundaries and epilogues; every epilogue option at once, operands and result as slices of
+    wider buffers.  Must equal the 128x128 kernel's result on the same operands to bf16 rounding, and an fp64
+    reference to 2^-8 relative."""
+    lib = bf16_ops
+    assert (m // 256) * (n // 128) >= 256
+    g = torch.Generator().manual_seed(m + n + k)
+    lda, ldc = k + 64, n + 32
+    abuf = torch.randn(m, lda, generator=g).bfloat16()
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).bfloat16()
+    bias, ps, s2, t2 = (torch.randn(n, generator=g) for _ in range(4))
+    pre, post = torch.randn(m, n, generator=g).bfloat16(), torch.randn(m, n + 32, generator=g).bfloat16()
+    a = abuf[:, 64:64 + k]
+    v = a.double() @ w.double().T + bias.double() + ps.double() * pre.double()
+    v = F.leaky_relu(v, 0.01) + post[:, :n].double()
+    ref = F.leaky_relu(v * s2.double() + t2.double(), 0.01)
+    D = lambda t: t.to(dev())
+    abuf_d, wd, bd, psd, s2d, t2d, pred, postd = map(D, (abuf, w, bias, ps, s2, t2, pre, post))
+    outs = []
+    for cfg in (6, 0, -1):          # wide forced, 128x128, the engine's own choice with gemm_wide on (= wide for these shapes)
+        cbuf = torch.full((m, ldc), -7.0, device=dev(), dtype=torch.bfloat16)
+        with options(gemm_cfg=cfg, gemm_wide=2 if cfg < 0 else 1):
+            ok(lib.casync_op_pw_gemm(abuf_d.data_ptr() + 64 * 2, lda, ptr(wd), ptr(bd), cbuf.data_ptr() + 16 * 2, ldc, m, n, k,
+                                     1, ptr(pred), n, ptr(psd), ptr(postd), n + 32, ptr(s2d), ptr(t2d), stream()))
+        out = cbuf.cpu()
+        assert (out[:, :16] == -7).all() and (out[:, 16 + n:] == -7).all()     # nothing outside the slice
+        outs.append(out[:, 16:16 + n].double())
+        err = (outs[-1] - ref).abs() / (ref.abs() + 1.0)
+        assert float(err.max()) < 2 ** -8, (cfg, float(err.max()))
+    # two roundings of nearly equal fp32 sums can land one bf16 ulp (2^-7 relative) apart
+    assert float(((outs[0] - outs[2]).abs() / (ref.abs() + 1.0)).max()) < 2 ** -7   # k-skew: another summation order
+    assert float(((outs[0] - outs[1]).abs() / (ref.abs() + 1.0)).max()) < 2 ** -7
+    # bit-repeatable, and a second launch right behind the first sees a clean ring
+    cbuf2 = torch.full((m, ldc), -7.0, device=dev(), dtype=torch.bfloat16)
+    with options(gemm_cfg=6):
+        for _ in range(2):
+            ok(lib.casync_op_pw_gemm(abuf_d.data_ptr() + 64 * 2, lda, ptr(wd), ptr(bd), cbuf2.data_ptr() + 16 * 2, ldc, m, n, k,
+                                     1, ptr(pred), n, ptr(psd), ptr(postd), n + 32, ptr(s2d), ptr(t2d), stream()))
+    assert torch.equal(cbuf2.cpu()[:, 16:16 + n].double(), outs[0])
+
+
+def test_pw_gemm_bf16_wide_kernel_plain(bf16_ops):
+    """No epilogue arithmetic: the wide kernel and the 128x128 kernel add the same products in the same k order."""
+    lib = bf16_ops
+    m, n, k = 32768, 256, 512
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(m, k, generator=g).bfloat16()
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).bfloat16()
+    bias = torch.randn(n, generator=g)
+    ref = a.double() @ w.double().T + bias.double()
+    ad, wd, bd = a.to(dev()), w.to(dev()), bias.to(dev())
+    outs = []
+    for cfg in (6, 0):
+        c = torch.empty(m, n, device=dev(), dtype=torch.bfloat16)
+        with options(gemm_cfg=cfg):
+            ok(lib.casync_op_pw_gemm(ptr(ad), k, ptr(wd), ptr(bd), ptr(c), n, m, n, k, 0, 0, 0, 0, 0, 0, 0, 0, stream()))
+        outs.append(c.cpu().double())
+        assert float(((outs[-1] - ref).abs() / (ref.abs() + 1.0)).max()) < 2 ** -8
+    assert torch.equal(outs[0], outs[1])     # no epilogue arithmetic: same fp32 sums, same rounding
+
+
 @pytest.mark.parametrize("prefix,cin,cout,stride,res,h,w", IR_CASES)
 def test_ir_fused_block_bf16(bf16_ops, recipe_sd, prefix, cin, cout, stride, res, h, w):
     """bf16 fused inverted residual (bf16 MFMA, bf16 E/D tiles) vs the fp32 oracle module on the
