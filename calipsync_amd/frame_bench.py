@@ -35,7 +35,7 @@ def run(net, dev, batch: int = 64, batches: int = 8, warmup: int = 2) -> dict:
     masks = [None] * batch
     feats = torch.from_numpy(np.random.default_rng(1).standard_normal((batch * (batches + warmup) + 16, 2, 1024))
                              .astype(np.float32)).to(dev)
-    def timed(pipelined: bool) -> float:
+    def timed(pipelined: bool, copy_frames: bool = True) -> float:
         prev = None
         n_out = 0
         for k in range(warmup + batches):
@@ -47,7 +47,8 @@ def run(net, dev, batch: int = 64, batches: int = 8, warmup: int = 2) -> dict:
                 t0 = time.perf_counter()
                 n_out = 0
             idx = list(range(k * batch, (k + 1) * batch))
-            cur = frame_loop.submit_batch_device(net, imgs, lms, masks, features=feats, frame_indices=idx)
+            cur = frame_loop.submit_batch_device(net, imgs, lms, masks, features=feats, frame_indices=idx,
+                                                 copy_frames=copy_frames)
             if pipelined:          # FrameSynthesizer.iterate_synthesized_frames: one batch in flight
                 if prev is not None:
                     n_out += len(prev.result())
@@ -64,10 +65,13 @@ def run(net, dev, batch: int = 64, batches: int = 8, warmup: int = 2) -> dict:
     dt_seq, dt_pipe = min(timed(False) for _ in range(1)), min(timed(True) for _ in range(1))
     for _ in range(2):
         dt_seq, dt_pipe = min(dt_seq, timed(False)), min(dt_pipe, timed(True))
+    dt_inplace = min(timed(True, False) for _ in range(3))
     side = int(np.mean([int(l[31][0]) - int(l[1][0]) for l in lms]))
     return {"frames_per_s": round(batch * batches / dt_pipe, 1), "ms_per_batch": round(1e3 * dt_pipe / batches, 2),
             "frames_per_s_batch_by_batch": round(batch * batches / dt_seq, 1),
-            "ms_per_batch_batch_by_batch": round(1e3 * dt_seq / batches, 2), "batch": batch,
+            "ms_per_batch_batch_by_batch": round(1e3 * dt_seq / batches, 2),
+            "frames_per_s_in_place": round(batch * batches / dt_inplace, 1),     # copy_frames=False: not the reference's contract
+            "batch": batch,
             "frame": "1920x1080 BGR uint8, synthetic", "mean_crop_side_px": side,
             "pipeline": "host crop-box slices into one pinned buffer -> 1 H2D -> resize168 -> forward_windows -> uint8 -> "
                         "resize back -> fillPoly -> dilate -> blend -> 1 D2H (pinned) -> paste into threaded frame copies "

@@ -117,6 +117,16 @@ def _host_pool():
     return _POOL
 
 
+class _Ready:
+    """A finished future (copy_frames=False: the frame itself stands in for its copy)."""
+
+    def __init__(self, value):
+        self._value = value
+
+    def result(self):
+        return self._value
+
+
 class PendingBatch:
     """A batch whose GPU work, frame copies and download are in flight (``submit_batch_device``); ``result()``
     waits for them and pastes the blended regions into the copied frames."""
@@ -129,14 +139,17 @@ class PendingBatch:
         if self._frames is None:
             self._done.synchronize()
             host = self._host.numpy()
-            frames = []
-            for i, fut in enumerate(self._copies):
-                out = fut.result()
+
+            def paste(i):
+                out = self._copies[i].result()
                 if self._geom[i, 4]:
                     ymin, ymax, xmin, xmax, _ = self._boxes[i]
                     h, w = ymax - ymin, xmax - xmin
                     out[ymin:ymax, xmin:xmax] = host[self._geom[i, 0]:self._geom[i, 0] + h * w * 3].reshape(h, w, 3)
-                frames.append(out)
+                return out
+
+            # (the copies were queued on the pool before these, so a paste never waits for a task behind it)
+            frames = [f.result() for f in [_host_pool().submit(paste, i) for i in range(len(self._copies))]]
             _release_pinned(self._host)
             if self._keep is not None:
                 _release_pinned(self._keep)
@@ -160,7 +173,7 @@ def _release_pinned(buf: torch.Tensor) -> None:
 
 
 def process_batch_device(net, batch_images, batch_landmarks, batch_masks, *, windows=None, features=None,
-                         frame_indices=None):
+                         frame_indices=None, copy_frames=True):
     """``FrameSynthesizer.process_batch`` with everything between the crop box and the pasted-back frame on the
     GPU: ONE upload (the crop regions of all frames, concatenated), cv2.resize -> model input -> ``net`` ->
     uint8 -> resize back -> polygon mask -> dilate -> blend, ONE download (the blended regions).
@@ -169,14 +182,18 @@ def process_batch_device(net, batch_images, batch_landmarks, batch_masks, *, win
     ``features`` [T,2,1024] on the device + ``frame_indices`` (windows gathered on the device).
     Returns the list of synthesised frames (copies; the inputs are not modified, like infer_api.py:201)."""
     return submit_batch_device(net, batch_images, batch_landmarks, batch_masks, windows=windows, features=features,
-                               frame_indices=frame_indices).result()
+                               frame_indices=frame_indices, copy_frames=copy_frames).result()
 
 
 def submit_batch_device(net, batch_images, batch_landmarks, batch_masks, *, windows=None, features=None,
-                        frame_indices=None) -> PendingBatch:
+                        frame_indices=None, copy_frames=True) -> PendingBatch:
     """The asynchronous half of ``process_batch_device``: host geometry, upload, every launch and the download
     are enqueued, the per-frame copies run on the host pool; nothing here waits for the GPU.  A caller that
-    submits batch k+1 before taking ``result()`` of batch k overlaps its host work with the GPU."""
+    submits batch k+1 before taking ``result()`` of batch k overlaps its host work with the GPU.
+
+    ``copy_frames=False`` gives up the reference's "the inputs are not modified" (infer_api.py:201): the blended
+    regions are pasted into ``batch_images`` themselves, which saves a 6 MB copy per 1080p frame -- the frame copies
+    are what bounds the end-to-end rate (400 MB per 64 frames against 57 MB of regions up and down)."""
     lib = _lib.load()
     dev = net._device()
     if dev.type != "cuda":
@@ -223,10 +240,6 @@ def submit_batch_device(net, batch_images, batch_landmarks, batch_masks, *, wind
     max_h, max_w = int(geom[:, 1].max()), int(geom[:, 2].max())
     max_width = int((geom[:, 3] * geom[:, 4]).max())
     stream = _stream(dev)
-    # The reference returns NEW frames (frame = img.copy(), infer_api.py:201).  64 copies of a 1080p frame are
-    # ~30 ms on one core, four times the GPU work of the batch, so they run on a small thread pool (NumPy copies
-    # release the GIL) while the GPU is busy, and only the paste waits for them.
-    copies = [_host_pool().submit(np.copy, img) for img in batch_images]
     # ONE pinned staging buffer, ONE upload: [crop regions | geom | pts | face masks], 16-B aligned parts
     al = lambda n: (n + 15) & ~15
     o_geom = al(reg_off)
@@ -235,15 +248,23 @@ def submit_batch_device(net, batch_images, batch_landmarks, batch_masks, *, wind
     total = o_fm + 4 * fmask_off
     stage = _acquire_pinned(total)
     st = stage.numpy()
-    off = 0
-    for r in regions:
+    pool = _host_pool()
+
+    def fill(dst_off, r):                       # one frame's crop region into its place in the pinned buffer
         n = r.shape[0] * r.shape[1] * 3
-        st[off:off + n].reshape(r.shape)[...] = r
-        off += n
+        st[dst_off:dst_off + n].reshape(r.shape)[...] = r
+
+    fills = [pool.submit(fill, int(geom[i, 0]), r) for i, r in enumerate(regions)]
+    # The reference returns NEW frames (frame = img.copy(), infer_api.py:201).  64 copies of a 1080p frame are
+    # ~30 ms on one core, four times the GPU work of the batch, so they run on the same small thread pool (NumPy
+    # copies release the GIL) behind the region copies, while the GPU is busy; only the paste waits for them.
+    copies = [pool.submit(np.copy, img) for img in batch_images] if copy_frames else [_Ready(img) for img in batch_images]
     st[o_geom:o_geom + geom.nbytes] = geom.reshape(-1).view(np.uint8)
     st[o_pts:o_pts + pts.nbytes] = pts.reshape(-1).view(np.uint8)
     if fmasks:
         st[o_fm:total] = np.concatenate(fmasks).view(np.uint8)
+    for f in fills:
+        f.result()
     with torch.cuda.device(dev):
         staged = torch.empty(total, dtype=torch.uint8, device=dev)
         staged.copy_(stage[:total], non_blocking=True)

@@ -224,6 +224,10 @@ def test_device_process_batch_equals_oracle(gpu_net, with_masks):
     assert np.array_equal(got[3], imgs[3])                                     # the shape-mismatch fallback
     assert any(not np.array_equal(g, im) for g, im in zip(got, imgs))          # and the others really changed
     assert all(np.array_equal(a, b) for a, b in zip(imgs, make_frames(7, 420, 560, seed=21, with_masks=with_masks)[0]))  # inputs intact
+    # copy_frames=False: same pixels, pasted into the caller's own arrays
+    mine = [im.copy() for im in imgs]
+    got2 = frame_loop.process_batch_device(gpu_net, mine, lms, masks, windows=wd, copy_frames=False)
+    assert all(g is m for g, m in zip(got2, mine)) and all(np.array_equal(g, w) for g, w in zip(got2, want))
 
 
 @pytest.mark.gpu
