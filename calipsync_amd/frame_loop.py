@@ -1,11 +1,20 @@
-"""Device-side pieces of the reference frame loop, host API.
+"""Device-side frame loop around the model, host API.
 
 The reference's ``FrameSynthesizer.process_batch`` (image_infer_v1/tools/frame_synthesizer/
 infer_api.py:192-357) does, per frame and on the CPU: crop + ``cv2.resize`` to 168x168, slice /
 mask / normalise / transpose / concat into the model input, one ``.cpu()`` per prediction, scale
-to uint8, resize back and blend.  The parts that are pure indexing are done here on the GPU in
-one launch per batch, bit-exactly; ``cv2.resize`` and the polygon blend keep their host code
-(their fixed-point arithmetic cannot be pinned without cv2)."""
+to uint8, resize back, ``fillPoly`` + ``dilate`` of the jaw polygon and a float64 blend into the frame.
+Here the host only computes the crop boxes and landmark transforms; everything between the crop box
+and the pasted-back region runs on the GPU (``casync_frame_prepare`` / ``casync_frame_paste_back``,
+csrc/frame_ops.hip), with one upload and one download per batch:
+
+* ``submit_batch_device`` / ``PendingBatch.result`` -- the asynchronous pair (one batch can be in flight
+  while the next is prepared), ``process_batch_device`` -- both in one call;
+* ``crops_to_model_input`` / ``predictions_to_uint8`` -- the two pure-indexing pieces on their own;
+* ``audio_windows_host`` / ``crop_box`` -- the host-side restatements the device path is tested against.
+
+The OpenCV arithmetic is restated bit for bit from its published algorithms (oracle/frame_ops_oracle.py);
+cv2 itself is absent from the build image, so that restatement is "parity unpinned" (tests/test_frame_ops.py)."""
 from __future__ import annotations
 
 import os
