@@ -105,6 +105,25 @@ def test_pw_gemm_epilogue_and_strides(lib):
     assert (out[:, :16] == -7).all() and (out[:, 16 + n:] == -7).all()     # nothing outside the slice
 
 
+def test_pw_gemm_operand_beyond_2gib_takes_the_pointer_addressed_kernel(lib):
+    """The ring kernels address A and W through buffer descriptors with 32-bit offsets; an operand whose extent
+    reaches 2 GiB (here: 4096 rows of a 2.3 GB buffer, lda = 140000 floats) must fall back to the register-staged
+    kernel and still be right."""
+    m, n, k, lda = 4096, 128, 64, 140000
+    assert ((m - 1) * lda + k) * 4 >= 2 ** 31
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / 8
+    b = torch.randn(n, generator=g)
+    abuf = torch.empty(m, lda, device=dev())
+    abuf[:, :k] = a.to(dev())
+    wd, bd = w.to(dev()), b.to(dev())
+    c = torch.empty(m, n, device=dev())
+    ok(lib.casync_op_pw_gemm(ptr(abuf), lda, ptr(wd), ptr(bd), ptr(c), n, m, n, k, 1, 0, 0, 0, 0, 0, 0, 0, stream()))
+    ref = F.leaky_relu(a.double() @ w.double().T + b.double(), 0.01).float()
+    assert rel_err(c.cpu(), ref) < 2e-6
+
+
 def test_pw_gemm_rejects_bad_shapes(lib):
     a = torch.zeros(64, 48, device=dev())
     assert lib.casync_op_pw_gemm(ptr(a), 48, ptr(a), 0, ptr(a), 48, 64, 48, 48, 0, 0, 0, 0, 0, 0, 0, 0, stream()) < 0
