@@ -18,6 +18,7 @@ cv2 itself is absent from the build image, so that restatement is "parity unpinn
 from __future__ import annotations
 
 import os
+import threading
 
 import torch
 
@@ -115,6 +116,12 @@ _POOL = None
 
 def _host_pool():
     global _POOL
+    with _PINNED_LOCK:
+        return _host_pool_locked()
+
+
+def _host_pool_locked():
+    global _POOL
     if _POOL is None:
         import concurrent.futures
         n = min(8, max(2, (os.cpu_count() or 2) // 2))
@@ -167,18 +174,23 @@ class PendingBatch:
 
 
 _PINNED = {}   # bytes (rounded up to 1 MiB) -> free pinned uint8 host buffers
+_PINNED_LOCK = threading.Lock()
 
 
 def _acquire_pinned(nbytes: int) -> torch.Tensor:
     size = max(1, (nbytes + (1 << 20) - 1) >> 20) << 20
-    free = _PINNED.setdefault(size, [])
-    return free.pop() if free else torch.empty(size, dtype=torch.uint8).pin_memory()
+    with _PINNED_LOCK:
+        free = _PINNED.setdefault(size, [])
+        if free:
+            return free.pop()
+    return torch.empty(size, dtype=torch.uint8).pin_memory()
 
 
 def _release_pinned(buf: torch.Tensor) -> None:
-    free = _PINNED.setdefault(buf.numel(), [])
-    if len(free) < 4:
-        free.append(buf)
+    with _PINNED_LOCK:
+        free = _PINNED.setdefault(buf.numel(), [])
+        if len(free) < 4:
+            free.append(buf)
 
 
 def process_batch_device(net, batch_images, batch_landmarks, batch_masks, *, windows=None, features=None,
