@@ -329,8 +329,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // 256 B of zeros: where the implicit-GEMM convolution points its LDS-DMA loads for taps outside the image
 __device__ __attribute__((aligned(256))) float g_zero_page[64];
 
+// waves per SIMD the register allocator must leave room for: the 64x64 two-stage ring needs 32 KB of LDS, so five
+// workgroups fit a CU -- if the kernel stays within 512 / 5 = 102 registers
+template <typename T, int BM, int BN, int NST, bool CONV>
+constexpr int glds_min_waves() { return sizeof(T) == 4 && BM == 64 && BN == 64 && NST == 2 && !CONV ? 5 : 1; }
+
 template <typename T, int BM, int BN, int WM, int WN, int NST, bool CONV = false>
-__global__ __launch_bounds__(256) void pw_gemm_glds_kernel(const T* __restrict__ A, int lda,
+__global__ __launch_bounds__(256, (glds_min_waves<T, BM, BN, NST, CONV>())) void pw_gemm_glds_kernel(const T* __restrict__ A, int lda,
                                                            const T* __restrict__ W, T* __restrict__ C,
                                                            int ldc, int M, int N, int K, int n_ntiles,
                                                            int nwg, int dp_tiles, int sk_wgs, int sk_per,
