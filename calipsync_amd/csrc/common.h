@@ -53,6 +53,7 @@ struct CasyncOptions {
   int gemm_glds = 2;         // CASYNC_GEMM_GLDS: LDS-DMA ring GEMM: 0 off, 1 bf16 only, 2 both types
   int gemm_cfg = -1;         // CASYNC_GEMM_CFG: force one tile configuration
   int gemm_pipe = 0;         // CASYNC_GEMM_PIPE: stages of the software-pipelined LDS-DMA ring, 3..6 (0 = the round-1 loop)
+  int gemm_arow = 0;         // CASYNC_GEMM_AROW: A-stationary kernel (A rows in registers, W streamed) for the bf16 plan's K = 256 / 512 GEMMs
   int gemm_wide = 0;         // CASYNC_GEMM_WIDE: 1 = 256x128 persistent ring kernel for the bf16 plan's large GEMMs (2 = with k-skew); measured equal to the 128x128 kernel, off
   int gemm_persist = 1;      // CASYNC_GEMM_PERSIST: persistent grid of the register-staged GEMM
   int lane_streamk = 0;      // CASYNC_LANE_STREAMK: stream-K also when two or more lanes run side by side (the other lane fills tails otherwise)

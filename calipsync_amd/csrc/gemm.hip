@@ -29,6 +29,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -817,6 +818,19 @@ __device__ __forceinline__ f32x4 lds_read16_raw(unsigned lds_addr) {
   return v;
 }
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant expression
+template <int... S, typename F>
+__device__ __forceinline__ void for_each_int(std::integer_sequence<int, S...>, F&& f) {
+  (f(std::integral_constant<int, S>{}), ...);
+}
+// workgroup barrier that waits for this wave's LDS operations only: vector-memory operations (LDS-DMA loads of
+// the next chunk, global stores of the epilogue) stay in flight across it
+__device__ __forceinline__ void __syncthreads_lds_only() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int NST>
 __global__ __launch_bounds__(64 * WM * WN) void pw_gemm_wide_kernel(const T* __restrict__ A, int lda,
                                                                     const T* __restrict__ W, T* __restrict__ C, int ldc,
@@ -1052,6 +1066,166 @@ int launch_wide_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, 
   return CASYNC_OK;
 }
 
+// =====================================================================================
+// A-stationary kernel for the bf16 plan's short-K GEMMs (K = 256 / 512, M = 256 frames x pixels per lane).
+// The ring kernels above spend their time filling LDS: every A row is read N / BN times and, shared by the eight
+// N-tiles of its M-block, arrives at first-touch latency (tools/experiments/lds_fill_rate.hip: 64 GB/s per CU for
+// that mix against 134 GB/s for an L2-resident operand).  Here a workgroup owns 128 rows of A for the whole N:
+//   * each wave keeps the MFMA A-fragments of ITS 32 rows over the whole K in registers (K / 16 x 16 B per lane,
+//     128 VGPRs at K = 512), loaded once from HBM -- A never touches LDS and is read exactly once;
+//   * W is streamed through LDS one 128-column chunk at a time, ALL its k-tiles at once (128 x K x 2 B = 128 KB at
+//     K = 512, L2-resident after the first workgroups have touched it): the loads of chunk c+1 are issued when the
+//     MFMAs of chunk c are done and land while the epilogue of chunk c runs, so the two phases alternate --
+//     MFMAs with nothing in flight / epilogue with the next chunk in flight -- and no counted wait is needed;
+//   * eight waves as 4 (rows) x 2 (64 columns each); fragment reads as raw ds_read_b128 (see pw_gemm_wide_kernel);
+//     the epilogue goes through 32 KB of staging next to the W area, 64 rows at a time.
+// Requires M % 128 == 0, N % 128 == 0, K = 16 * KSTEPS with KSTEPS in {16, 32}, operands < 2 GiB.
+// =====================================================================================
+template <typename T, int KSTEPS>
+__global__ __launch_bounds__(512) void pw_gemm_arow_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W,
+                                                           T* __restrict__ C, int ldc, int M, int N, GemmEpilogue epi) {
+  static_assert(sizeof(T) == 2, "bf16 only");
+  constexpr int K = 16 * KSTEPS, NKT = K / 64;          // k-tiles of 64 (128-B rows)
+  constexpr int BM = 128, BN = 128, NW = 8, NT = 512;
+  constexpr int TILE = BN * ROWB;                        // one k-tile of the W chunk in LDS: [128][128 B] = 16 KB
+  constexpr int LPT = BN / (8 * NW);                     // LDS-DMA instructions per wave per k-tile (= 2)
+  constexpr int HALF = 64;                               // epilogue staging: HALF x BN floats = 32 KB
+  static_assert((size_t)NKT * TILE + (size_t)HALF * BN * 4 <= 160 * 1024, "LDS budget");
+  extern __shared__ __attribute__((aligned(16))) char wlds[];
+  float* Cs = reinterpret_cast<float*>(wlds + (size_t)NKT * TILE);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r32 = lane & 31, kh = lane >> 5;
+  const int lrow8 = lane >> 3, lcol = lane & 7;
+  const int m0 = (int)blockIdx.x * BM;
+
+  // ---- A fragments: row m0 + 32 wm + r32, k = 16 s + 8 kh .. +7 for every k-step s: HBM -> registers, once ----
+  f32x4 fa[KSTEPS];
+  {
+    const T* arow = A + (size_t)(m0 + 32 * wm + r32) * lda + 8 * kh;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) fa[s] = *reinterpret_cast<const f32x4*>(arow + 16 * s);
+  }
+
+  // ---- W chunk loads: k-tile kt of chunk n0 -> wlds + kt * TILE, rows swizzled through the source address ----
+  int voff[LPT];
+#pragma unroll
+  for (int j = 0; j < LPT; ++j) {
+    const int r = (j * NW + wave) * 8 + lrow8;           // W row inside the chunk
+    voff[j] = r * K * (int)sizeof(T) + (lcol ^ ((r >> 1) & 7)) * 16;
+  }
+  auto issue_chunk = [&](int n0) __attribute__((always_inline)) {
+    const int base = n0 * K * (int)sizeof(T);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int j = 0; j < LPT; ++j)
+        buffer_load_lds16(W, epi.buf_w_bytes,
+                          (void __attribute__((address_space(3)))*)(wlds + kt * TILE + (j * NW + wave_s) * 8 * ROWB), voff[j],
+                          base + kt * ROWB);
+  };
+
+  // ---- B fragment addresses: row wn*64 + j*32 + r32 of the chunk, 16-B column 2g + kh of a k-tile; the k-tile
+  //      offset goes into the instruction's 16-bit offset field, so k-tiles 4..7 get a second set of bases ----
+  const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(wlds);
+  unsigned b_adr[2][2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int r = wn * 64 + j * 32 + r32;
+      b_adr[0][j][g] = lds0 + r * ROWB + (((2 * g + kh) ^ ((r >> 1) & 7)) << 4);
+      b_adr[1][j][g] = b_adr[0][j][g] + 4 * TILE;
+    }
+
+  // diagnostic stamps (epi.stamps, null in every product call): entry, chunk 0 landed, its MFMAs done, its epilogue
+  // done, chunk 1 landed, exit; chunks; shader cycles
+  auto stamp = [&](int slot) __attribute__((always_inline)) {
+    if (epi.stamps && tid == 0) epi.stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+  };
+  const unsigned long long cyc0 = epi.stamps ? __builtin_amdgcn_s_memtime() : 0;
+  stamp(0);
+  f32x16 acc[2];
+  issue_chunk(0);
+  for (int n0 = 0; n0 < N; n0 += BN) {
+    wait_vmcnt<0>();                 // this chunk of W has landed (and the previous epilogue's stores are out)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (n0 == 0) stamp(1);
+    if (n0 == BN) stamp(4);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+    // MFMAs over the whole K; two fragment sets so that the reads of the next k-step sit under the current MFMAs
+    f32x4 fb[2][2];
+#define CASYNC_AROW_WAIT(N, x) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x[0]), "+v"(x[1]))
+    fb[0][0] = lds_read16_raw<0>(b_adr[0][0][0]);
+    fb[0][1] = lds_read16_raw<0>(b_adr[0][1][0]);
+    for_each_int(std::make_integer_sequence<int, KSTEPS>{}, [&](auto s_c) __attribute__((always_inline)) {
+      constexpr int S = decltype(s_c)::value, CUR = S & 1, NXT = CUR ^ 1;
+      if constexpr (S + 1 < KSTEPS) {      // k-step S+1: k-tile (S+1)/4, column pair (S+1)%4
+        constexpr int KT = (S + 1) >> 2, G = (S + 1) & 3, SET = KT >> 2, OFF = (KT & 3) * TILE;
+        fb[NXT][0] = lds_read16_raw<OFF>(b_adr[SET][0][G]);
+        fb[NXT][1] = lds_read16_raw<OFF>(b_adr[SET][1][G]);
+        CASYNC_AROW_WAIT(2, fb[CUR]);
+      } else {
+        CASYNC_AROW_WAIT(0, fb[CUR]);
+      }
+      acc[0] = MfmaK<T>::run(fa[S], fb[CUR][0], acc[0]);
+      acc[1] = MfmaK<T>::run(fa[S], fb[CUR][1], acc[1]);
+    });
+#undef CASYNC_AROW_WAIT
+    __builtin_amdgcn_s_barrier();    // every wave is done reading this chunk of W
+    asm volatile("" ::: "memory");
+    if (n0 == 0) stamp(2);
+    // ---- epilogue: rows 64 h .. 64 h + 63 through the staging area.  The per-column constants are requested
+    //      BEFORE the next chunk of W: vector-memory operations retire in order, so behind the 128 KB of W they
+    //      would arrive a microsecond later ----
+    EpiCols<T> cols;
+    cols.load(epi, n0 + (tid % (BN / V16<T>::N)) * V16<T>::N);
+    if (n0 + BN < N) issue_chunk(n0 + BN);   // lands while the epilogue runs
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if ((wm >> 1) == h) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = 32 * (wm & 1) + 4 * kh + (r & 3) + 8 * (r >> 2);      // bit 2 of the row = kh
+            Cs[row * BN + ((wn * 64 + j * 32 + r32) ^ (kh << 5))] = acc[j][r];
+          }
+      }
+      __syncthreads_lds_only();
+      epilogue_rows_cols<T, NT, HALF, BN, 0, true>(Cs, m0 + HALF * h, n0, M, C, ldc, epi, tid, cols);
+      __syncthreads_lds_only();
+    }
+    if (n0 == 0) stamp(3);
+  }
+  stamp(5);
+  if (epi.stamps && tid == 0) {
+    epi.stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)(N / BN);
+    epi.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - cyc0;
+  }
+}
+
+template <typename T, int KSTEPS>
+int launch_arow_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, const GemmEpilogue& epi, hipStream_t stream) {
+  constexpr int K = 16 * KSTEPS;
+  constexpr size_t lds = (size_t)(K / 64) * 128 * ROWB + (size_t)64 * 128 * sizeof(float);
+  static unsigned long long attr_once = 0;
+  auto kern = pw_gemm_arow_kernel<T, KSTEPS>;
+  if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)lds)) return st;
+  CASYNC_REQUIRE(m % 128 == 0 && n % 128 == 0, "a-stationary gemm: shape m=%d n=%d", m, n);
+  const unsigned long long wb = (unsigned long long)n * K * sizeof(T);
+  CASYNC_REQUIRE(wb < (1ull << 31), "gemm: operand larger than 2 GiB");
+  GemmEpilogue e2 = epi;
+  e2.buf_w_bytes = (unsigned)wb;
+  hipLaunchKernelGGL(kern, dim3(m / 128), dim3(512), lds, stream, a, lda, w, c, ldc, m, n, e2);
+  CASYNC_CHECK_HIP(hipGetLastError());
+  return CASYNC_OK;
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, int k,
                  const GemmEpilogue& epi, hipStream_t stream) {
@@ -1126,12 +1300,16 @@ int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, i
 // Tile choice.  On a 256-CU chip a launch of G workgroups finishes after ceil(G/256) "rounds" of
 // one tile per CU (co-resident tiles share the CU's matrix pipes, so they add, not overlap);
 // pick the tile that minimises rounds x tile area, preferring the larger tile on ties.
-enum Cfg { C128x128 = 0, C128x64, C64x64, C128x32, C64x32, C64x64W2, C256x128, CFG_COUNT };
+enum Cfg { C128x128 = 0, C128x64, C64x64, C128x32, C64x32, C64x64W2, C256x128, CAROW, CFG_COUNT };
 
 struct TileCfg { Cfg id; int bm, bn; };
 constexpr TileCfg kTiles[] = {{C128x128, 128, 128}, {C128x64, 128, 64}, {C64x64, 64, 64}, {C128x32, 128, 32},
-                              {C64x32, 64, 32}, {C64x64W2, 64, 64}, {C256x128, 256, 128}};
+                              {C64x32, 64, 32}, {C64x64W2, 64, 64}, {C256x128, 256, 128}, {CAROW, 128, 128}};
 
+// the A-stationary kernel (pw_gemm_arow_kernel): bf16, K = 256 / 512, whole 128-row blocks, at least half a chip of them
+bool takes_arow(int m, int n, int k, int dtype) {
+  return dtype == DT_BF16 && m % 128 == 0 && n % 128 == 0 && (k == 256 || k == 512) && m / 128 >= 128;
+}
 // the wide persistent ring kernel (pw_gemm_wide_kernel): bf16, whole 256x128 tiles, at least one per CU
 bool takes_wide(int m, int n, int k, int dtype) {
   return dtype == DT_BF16 && m % 256 == 0 && n % 128 == 0 && k / (ROWB / 2) >= 4 && (long long)(m / 256) * (n / 128) >= 256;
@@ -1148,7 +1326,8 @@ int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullp
   const int forced = casync_opts().gemm_cfg;
   const int nk = k / (ROWB / dtype_size(dtype));
   if (use_sk) *use_sk = false;
-  if (forced == C256x128 ? takes_wide(m, n, k, dtype) : forced >= 0 && forced < CFG_COUNT && n % kTiles[forced].bn == 0) {
+  if (forced == CAROW ? takes_arow(m, n, k, dtype)
+                      : forced == C256x128 ? takes_wide(m, n, k, dtype) : forced >= 0 && forced < CFG_COUNT && n % kTiles[forced].bn == 0) {
     const TileCfg& t = kTiles[forced];
     const long long g = (long long)((m + t.bm - 1) / t.bm) * (n / t.bn);
     if (use_sk) *use_sk = takes_ring(t, g, dtype) && stream_k_split(g, nk, t.bm * t.bn, stream_k).wgs > 0;
@@ -1160,6 +1339,7 @@ int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullp
   // +600 is the worse operand reuse of small tiles.  Stream-K makes the last round fractional
   // and adds ~5 us (64x64) to ~10 us (128x64) of short-run start-up, parking and fix-up (priced
   // a little higher here so that it is only chosen where it clearly wins).
+  if (casync_opts().gemm_arow && forced < 0 && takes_arow(m, n, k, dtype)) return CAROW;
   if (casync_opts().gemm_wide && forced < 0 && takes_wide(m, n, k, dtype)) return C256x128;
   const int conc_mode = casync_opts().gemm_conc, conc_tiles = casync_opts().gemm_conc_tiles;
   const long long t64 = (long long)((m + 63) / 64) * (n / 64);
@@ -1208,7 +1388,9 @@ const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype, b
   }
   const TileCfg& tc = kTiles[id];
   const long long tiles = (long long)((m + tc.bm - 1) / tc.bm) * (n / tc.bn);
-  if (id == C256x128)
+  if (id == CAROW)
+    snprintf(buf, sizeof(buf), "pw_gemm_arow_kernel<%s, %d>", t, k / 16);
+  else if (id == C256x128)
     snprintf(buf, sizeof(buf), "pw_gemm_wide_kernel<%s, 256, 128, 4, 2, 3>", t);
   else if (takes_ring(tc, tiles, dtype))
     snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, %d, false>", t, cfg,
@@ -1244,6 +1426,15 @@ int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int 
     case C64x64: return launch_cfg<64, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
     case C64x32: return launch_cfg<64, 32, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
     case C64x64W2: return launch_cfg<64, 64, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
+    case CAROW:
+      if ((size_t)n * k * 2 < (1ull << 31)) {
+        const bf16_t* ab = static_cast<const bf16_t*>(a);
+        const bf16_t* wbp = static_cast<const bf16_t*>(w);
+        bf16_t* cb = static_cast<bf16_t*>(c);
+        return k == 512 ? launch_arow_t<bf16_t, 32>(ab, lda, wbp, cb, ldc, m, n, epi, stream)
+                        : launch_arow_t<bf16_t, 16>(ab, lda, wbp, cb, ldc, m, n, epi, stream);
+      }
+      return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
     case C256x128:
       if (((size_t)(m - 1) * lda + k) * 2 < (1ull << 31) && (size_t)n * k * 2 < (1ull << 31))
         return launch_wide_t<bf16_t, 256, 128, 4, 2, 3>(static_cast<const bf16_t*>(a), lda, static_cast<const bf16_t*>(w),

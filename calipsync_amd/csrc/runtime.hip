@@ -23,6 +23,7 @@ const OptField kFields[] = {
     {"gemm_glds", &CasyncOptions::gemm_glds},
     {"gemm_cfg", &CasyncOptions::gemm_cfg},
     {"gemm_pipe", &CasyncOptions::gemm_pipe},
+    {"gemm_arow", &CasyncOptions::gemm_arow},
     {"gemm_wide", &CasyncOptions::gemm_wide},
     {"gemm_persist", &CasyncOptions::gemm_persist},
     {"lane_streamk", &CasyncOptions::lane_streamk},

@@ -367,15 +367,11 @@ def test_pw_gemm_bf16(bf16_ops, m, n, k):
     assert float(err.max()) < 2 ** -8, float(err.max())
 
 
-@pytest.mark.parametrize("m,n,k", [(65536, 128, 256), (16384, 512, 512), (25600, 1024, 512), (16384, 640, 1024),
-                                   (8192, 1024, 4096)])
-def test_pw_gemm_bf16_wide_kernel(bf16_ops, m, n, k):
-    """The 256x128 persistent ring kernel (bf16 plan, >= 256 tiles): several tiles per workgroup, so the ring
-    runs across tile boundaries and epilogues; every epilogue option at once, operands and result as slices of
-    wider buffers.  Must equal the 128x128 kernel's result on the same operands to bf16 rounding, and an fp64
-    reference to 2^-8 relative."""
-    lib = bf16_ops
-    assert (m // 256) * (n // 128) >= 256
+def _bf16_big_gemm_check(lib, m, n, k, cfg, switch):
+    """One of the two large-M bf16 kernels (cfg 6 = 256x128 persistent ring, 7 = A-stationary) with every epilogue
+    option at once and operands / result as slices of wider buffers: equal to an fp64 reference to 2^-8 relative,
+    one bf16 ulp from the 128x128 kernel on the same operands, bit-repeatable, nothing written outside the slice;
+    `switch` = the option that makes the engine pick that kernel by itself."""
     g = torch.Generator().manual_seed(m + n + k)
     lda, ldc = k + 64, n + 32
     abuf = torch.randn(m, lda, generator=g).bfloat16()
@@ -388,27 +384,44 @@ def test_pw_gemm_bf16_wide_kernel(bf16_ops, m, n, k):
     ref = F.leaky_relu(v * s2.double() + t2.double(), 0.01)
     D = lambda t: t.to(dev())
     abuf_d, wd, bd, psd, s2d, t2d, pred, postd = map(D, (abuf, w, bias, ps, s2, t2, pre, post))
+
+    def run(out_buf):
+        ok(lib.casync_op_pw_gemm(abuf_d.data_ptr() + 64 * 2, lda, ptr(wd), ptr(bd), out_buf.data_ptr() + 16 * 2, ldc, m, n, k,
+                                 1, ptr(pred), n, ptr(psd), ptr(postd), n + 32, ptr(s2d), ptr(t2d), stream()))
     outs = []
-    for cfg in (6, 0, -1):          # wide forced, 128x128, the engine's own choice with gemm_wide on (= wide for these shapes)
+    for opts in ({"gemm_cfg": cfg}, {"gemm_cfg": 0}, {"gemm_cfg": -1, **switch}):
         cbuf = torch.full((m, ldc), -7.0, device=dev(), dtype=torch.bfloat16)
-        with options(gemm_cfg=cfg, gemm_wide=2 if cfg < 0 else 1):
-            ok(lib.casync_op_pw_gemm(abuf_d.data_ptr() + 64 * 2, lda, ptr(wd), ptr(bd), cbuf.data_ptr() + 16 * 2, ldc, m, n, k,
-                                     1, ptr(pred), n, ptr(psd), ptr(postd), n + 32, ptr(s2d), ptr(t2d), stream()))
+        with options(**opts):
+            run(cbuf)
         out = cbuf.cpu()
         assert (out[:, :16] == -7).all() and (out[:, 16 + n:] == -7).all()     # nothing outside the slice
         outs.append(out[:, 16:16 + n].double())
         err = (outs[-1] - ref).abs() / (ref.abs() + 1.0)
-        assert float(err.max()) < 2 ** -8, (cfg, float(err.max()))
+        assert float(err.max()) < 2 ** -8, (opts, float(err.max()))
     # two roundings of nearly equal fp32 sums can land one bf16 ulp (2^-7 relative) apart
-    assert float(((outs[0] - outs[2]).abs() / (ref.abs() + 1.0)).max()) < 2 ** -7   # k-skew: another summation order
     assert float(((outs[0] - outs[1]).abs() / (ref.abs() + 1.0)).max()) < 2 ** -7
-    # bit-repeatable, and a second launch right behind the first sees a clean ring
+    assert float(((outs[0] - outs[2]).abs() / (ref.abs() + 1.0)).max()) < 2 ** -7
     cbuf2 = torch.full((m, ldc), -7.0, device=dev(), dtype=torch.bfloat16)
-    with options(gemm_cfg=6):
-        for _ in range(2):
-            ok(lib.casync_op_pw_gemm(abuf_d.data_ptr() + 64 * 2, lda, ptr(wd), ptr(bd), cbuf2.data_ptr() + 16 * 2, ldc, m, n, k,
-                                     1, ptr(pred), n, ptr(psd), ptr(postd), n + 32, ptr(s2d), ptr(t2d), stream()))
+    with options(gemm_cfg=cfg):
+        for _ in range(2):      # bit-repeatable, and a second launch right behind the first sees clean state
+            run(cbuf2)
     assert torch.equal(cbuf2.cpu()[:, 16:16 + n].double(), outs[0])
+
+
+@pytest.mark.parametrize("m,n,k", [(65536, 128, 256), (16384, 512, 512), (25600, 1024, 512), (16384, 640, 1024),
+                                   (8192, 1024, 4096)])
+def test_pw_gemm_bf16_wide_kernel(bf16_ops, m, n, k):
+    """The 256x128 persistent ring kernel (>= 256 tiles): several tiles per workgroup, so the ring runs across
+    tile boundaries and epilogues."""
+    assert (m // 256) * (n // 128) >= 256
+    _bf16_big_gemm_check(bf16_ops, m, n, k, 6, {"gemm_wide": 2})
+
+
+@pytest.mark.parametrize("m,n,k", [(65536, 128, 256), (16384, 512, 512), (25600, 1024, 512), (16384, 640, 256),
+                                   (32768, 2304, 512)])
+def test_pw_gemm_bf16_a_stationary_kernel(bf16_ops, m, n, k):
+    """The A-stationary kernel: A rows in registers, W streamed chunk by chunk; several chunks per workgroup."""
+    _bf16_big_gemm_check(bf16_ops, m, n, k, 7, {"gemm_arow": 1})
 
 
 def test_pw_gemm_bf16_wide_kernel_plain(bf16_ops):
