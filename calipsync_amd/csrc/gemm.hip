@@ -80,9 +80,18 @@ struct EpiCols {
   }
 };
 
+// column constant e of a thread: from the register copy, or (LITE) straight from memory / the default when absent
+template <bool LITE>
+__device__ __forceinline__ float col_const(const float* regs, const float* mem, float dflt, int n, int e) {
+  if constexpr (LITE) return mem ? mem[n + e] : dflt;
+  else return regs[e];
+}
+
 // PAD: floats of padding per staged row; SWZ: the staging tile has no padding and column bit 5 is flipped on rows
 // with bit 2 set instead (the wide kernel's 32-row slabs: the two lane halves of an MFMA C register are 4 rows apart).
-template <typename T, int NT, int BM, int BN, int PAD = 4, bool SWZ = false>
+// LITE: only k.bias is held in registers; the rarely used per-column vectors (pre-residual scale, second affine) are
+// fetched where they are used (the A-stationary kernel has 128 registers of A fragments live across its epilogue).
+template <typename T, int NT, int BM, int BN, int PAD = 4, bool SWZ = false, bool LITE = false>
 __device__ __forceinline__ void epilogue_rows_cols(const float* Cs, int m0, int n0, int M, T* __restrict__ C, int ldc,
                                                    const GemmEpilogue& epi, int tid, const EpiCols<T>& k) {
   constexpr int CPT = V16<T>::N, TPR = BN / CPT, RPP = NT / TPR, LDC_S = BN + PAD;
@@ -102,7 +111,7 @@ __device__ __forceinline__ void epilogue_rows_cols(const float* Cs, int m0, int 
     if (epi.pre_res) {
       const V16<T> r = ld16(static_cast<const T*>(epi.pre_res) + (size_t)m * epi.ld_pre + n);
 #pragma unroll
-      for (int e = 0; e < CPT; ++e) v.v[e] += k.pscale[e] * r.v[e];
+      for (int e = 0; e < CPT; ++e) v.v[e] += col_const<LITE>(k.pscale, epi.pre_scale, 1.f, n, e) * r.v[e];
     }
     if (epi.act) {
 #pragma unroll
@@ -115,7 +124,8 @@ __device__ __forceinline__ void epilogue_rows_cols(const float* Cs, int m0, int 
     }
     if (epi.aff_s && !epi.aff_on_acc) {
 #pragma unroll
-      for (int e = 0; e < CPT; ++e) v.v[e] = lrelu(v.v[e] * k.as[e] + k.at[e]);
+      for (int e = 0; e < CPT; ++e)
+        v.v[e] = lrelu(v.v[e] * col_const<LITE>(k.as, epi.aff_s, 1.f, n, e) + col_const<LITE>(k.at, epi.aff_t, 0.f, n, e));
     }
     st16(C + (size_t)m * ldc + n, v);
     if (epi.acc_out) {
@@ -124,7 +134,8 @@ __device__ __forceinline__ void epilogue_rows_cols(const float* Cs, int m0, int 
       for (int e = 0; e < CPT; ++e) sacc.v[e] += v.v[e];
       if (epi.aff_s && epi.aff_on_acc) {
 #pragma unroll
-        for (int e = 0; e < CPT; ++e) sacc.v[e] = lrelu(sacc.v[e] * k.as[e] + k.at[e]);
+        for (int e = 0; e < CPT; ++e)
+          sacc.v[e] = lrelu(sacc.v[e] * col_const<LITE>(k.as, epi.aff_s, 1.f, n, e) + col_const<LITE>(k.at, epi.aff_t, 0.f, n, e));
       }
       st16(static_cast<T*>(epi.acc_out) + (size_t)m * epi.ld_acc + n, sacc);
     }
@@ -1116,10 +1127,10 @@ __global__ __launch_bounds__(512) void pw_gemm_arow_kernel(const T* __restrict__
     const int r = (j * NW + wave) * 8 + lrow8;           // W row inside the chunk
     voff[j] = r * K * (int)sizeof(T) + (lcol ^ ((r >> 1) & 7)) * 16;
   }
-  auto issue_chunk = [&](int n0) __attribute__((always_inline)) {
+  auto issue_tiles = [&](int n0, auto lo_c, auto hi_c) __attribute__((always_inline)) {   // k-tiles [lo, hi) of chunk n0
     const int base = n0 * K * (int)sizeof(T);
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+    for (int kt = decltype(lo_c)::value; kt < decltype(hi_c)::value; ++kt)
 #pragma unroll
       for (int j = 0; j < LPT; ++j)
         buffer_load_lds16(W, epi.buf_w_bytes,
@@ -1128,16 +1139,15 @@ __global__ __launch_bounds__(512) void pw_gemm_arow_kernel(const T* __restrict__
   };
 
   // ---- B fragment addresses: row wn*64 + j*32 + r32 of the chunk, 16-B column 2g + kh of a k-tile; the k-tile
-  //      offset goes into the instruction's 16-bit offset field, so k-tiles 4..7 get a second set of bases ----
+  //      offset goes into the instruction's 16-bit offset field (k-tiles 4..7: base + 64 KB, one add per read) ----
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(wlds);
-  unsigned b_adr[2][2][4];
+  unsigned b_adr[2][4];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int r = wn * 64 + j * 32 + r32;
-      b_adr[0][j][g] = lds0 + r * ROWB + (((2 * g + kh) ^ ((r >> 1) & 7)) << 4);
-      b_adr[1][j][g] = b_adr[0][j][g] + 4 * TILE;
+      b_adr[j][g] = lds0 + r * ROWB + (((2 * g + kh) ^ ((r >> 1) & 7)) << 4);
     }
 
   // diagnostic stamps (epi.stamps, null in every product call): entry, chunk 0 landed, its MFMAs done, its epilogue
@@ -1148,7 +1158,8 @@ __global__ __launch_bounds__(512) void pw_gemm_arow_kernel(const T* __restrict__
   const unsigned long long cyc0 = epi.stamps ? __builtin_amdgcn_s_memtime() : 0;
   stamp(0);
   f32x16 acc[2];
-  issue_chunk(0);
+  using std::integral_constant;
+  issue_tiles(0, integral_constant<int, 0>{}, integral_constant<int, NKT>{});
   for (int n0 = 0; n0 < N; n0 += BN) {
     wait_vmcnt<0>();                 // this chunk of W has landed (and the previous epilogue's stores are out)
     __builtin_amdgcn_s_barrier();
@@ -1160,14 +1171,23 @@ __global__ __launch_bounds__(512) void pw_gemm_arow_kernel(const T* __restrict__
     // MFMAs over the whole K; two fragment sets so that the reads of the next k-step sit under the current MFMAs
     f32x4 fb[2][2];
 #define CASYNC_AROW_WAIT(N, x) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x[0]), "+v"(x[1]))
-    fb[0][0] = lds_read16_raw<0>(b_adr[0][0][0]);
-    fb[0][1] = lds_read16_raw<0>(b_adr[0][1][0]);
+    fb[0][0] = lds_read16_raw<0>(b_adr[0][0]);
+    fb[0][1] = lds_read16_raw<0>(b_adr[1][0]);
     for_each_int(std::make_integer_sequence<int, KSTEPS>{}, [&](auto s_c) __attribute__((always_inline)) {
       constexpr int S = decltype(s_c)::value, CUR = S & 1, NXT = CUR ^ 1;
+      if constexpr (S == KSTEPS / 2 + 1) {
+        // every wave has issued its last read of the first half of the k-tiles (the reads of k-step KSTEPS/2
+        // were issued one step ago): after a barrier that half of the W area is free, and the first half of
+        // the next chunk is requested here, under the MFMAs of the second half, instead of in one burst of
+        // sixteen LDS-DMA instructions (60-180 issue cycles each) in front of the epilogue
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]));
+        __builtin_amdgcn_s_barrier();
+        if (n0 + BN < N) issue_tiles(n0 + BN, integral_constant<int, 0>{}, integral_constant<int, NKT / 2>{});
+      }
       if constexpr (S + 1 < KSTEPS) {      // k-step S+1: k-tile (S+1)/4, column pair (S+1)%4
         constexpr int KT = (S + 1) >> 2, G = (S + 1) & 3, SET = KT >> 2, OFF = (KT & 3) * TILE;
-        fb[NXT][0] = lds_read16_raw<OFF>(b_adr[SET][0][G]);
-        fb[NXT][1] = lds_read16_raw<OFF>(b_adr[SET][1][G]);
+        fb[NXT][0] = lds_read16_raw<OFF>(b_adr[0][G] + SET * 4 * TILE);
+        fb[NXT][1] = lds_read16_raw<OFF>(b_adr[1][G] + SET * 4 * TILE);
         CASYNC_AROW_WAIT(2, fb[CUR]);
       } else {
         CASYNC_AROW_WAIT(0, fb[CUR]);
@@ -1182,9 +1202,13 @@ __global__ __launch_bounds__(512) void pw_gemm_arow_kernel(const T* __restrict__
     // ---- epilogue: rows 64 h .. 64 h + 63 through the staging area.  The per-column constants are requested
     //      BEFORE the next chunk of W: vector-memory operations retire in order, so behind the 128 KB of W they
     //      would arrive a microsecond later ----
+    // (the thread index is made opaque per chunk: otherwise the row pointers of the epilogue are hoisted out of
+    //  the chunk loop, do not fit beside the A fragments, get spilled, and their reloads queue up behind the LDS-DMA)
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));
     EpiCols<T> cols;
-    cols.load(epi, n0 + (tid % (BN / V16<T>::N)) * V16<T>::N);
-    if (n0 + BN < N) issue_chunk(n0 + BN);   // lands while the epilogue runs
+    cols.load(epi, n0 + (tid_e % (BN / V16<T>::N)) * V16<T>::N);
+    if (n0 + BN < N) issue_tiles(n0 + BN, integral_constant<int, NKT / 2>{}, integral_constant<int, NKT>{});   // lands while the epilogue runs
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if ((wm >> 1) == h) {
@@ -1197,7 +1221,7 @@ __global__ __launch_bounds__(512) void pw_gemm_arow_kernel(const T* __restrict__
           }
       }
       __syncthreads_lds_only();
-      epilogue_rows_cols<T, NT, HALF, BN, 0, true>(Cs, m0 + HALF * h, n0, M, C, ldc, epi, tid, cols);
+      epilogue_rows_cols<T, NT, HALF, BN, 0, true, true>(Cs, m0 + HALF * h, n0, M, C, ldc, epi, tid_e, cols);
       __syncthreads_lds_only();
     }
     if (n0 == 0) stamp(3);
@@ -1308,7 +1332,8 @@ constexpr TileCfg kTiles[] = {{C128x128, 128, 128}, {C128x64, 128, 64}, {C64x64,
 
 // the A-stationary kernel (pw_gemm_arow_kernel): bf16, K = 256 / 512, whole 128-row blocks, at least half a chip of them
 bool takes_arow(int m, int n, int k, int dtype) {
-  return dtype == DT_BF16 && m % 128 == 0 && n % 128 == 0 && (k == 256 || k == 512) && m / 128 >= 128;
+  return dtype == DT_BF16 && m % 128 == 0 && n % 128 == 0 && (k == 512 || (k == 256 && casync_opts().gemm_arow >= 2)) &&
+         m / 128 >= 128;   // K = 256 leaves two thirds of LDS unused by a lone workgroup per CU and measured equal
 }
 // the wide persistent ring kernel (pw_gemm_wide_kernel): bf16, whole 256x128 tiles, at least one per CU
 bool takes_wide(int m, int n, int k, int dtype) {
@@ -1326,7 +1351,7 @@ int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullp
   const int forced = casync_opts().gemm_cfg;
   const int nk = k / (ROWB / dtype_size(dtype));
   if (use_sk) *use_sk = false;
-  if (forced == CAROW ? takes_arow(m, n, k, dtype)
+  if (forced == CAROW ? (takes_arow(m, n, k, dtype) || (dtype == DT_BF16 && m % 128 == 0 && n % 128 == 0 && k == 256 && m / 128 >= 128))
                       : forced == C256x128 ? takes_wide(m, n, k, dtype) : forced >= 0 && forced < CFG_COUNT && n % kTiles[forced].bn == 0) {
     const TileCfg& t = kTiles[forced];
     const long long g = (long long)((m + t.bm - 1) / t.bm) * (n / t.bn);
