@@ -85,7 +85,9 @@ ABI_VERSION = 2          # == CASYNC_ABI_VERSION of include/casync_hip.h this fi
 
 
 def lib_path() -> str:
-    return _build.LIB_PATH
+    """The in-tree library; CASYNC_LIB names another build of the same ABI (A/B runs of two kernel versions in one
+    GPU session: tools/experiments).  An override is never rebuilt."""
+    return os.environ.get("CASYNC_LIB") or _build.LIB_PATH
 
 
 def load() -> C.CDLL:
@@ -102,7 +104,7 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"casync HIP engine not built: {path} is missing. Run `python -c 'import "
             "__graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
-    if _build.is_stale():
+    if path == _build.LIB_PATH and _build.is_stale():
         # a library older than its sources can carry an old struct stride / prototype: rebuild where a
         # compiler exists (the build container, the GPU box), refuse it otherwise
         try:

@@ -28,7 +28,7 @@ def _newer(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
 def _header_paths():
@@ -36,8 +36,22 @@ def _header_paths():
 
 
 def is_stale() -> bool:
-    """True when the library is missing or older than any of its sources / headers."""
+    """True when the library is missing or older than any of its sources / headers.  A deployment that ships the
+    library without csrc/ has nothing to be stale against: missing sources count as "not newer"."""
     return _newer(LIB_PATH, [os.path.join(CSRC, s) for s in SOURCES] + _header_paths())
+
+
+def source_hash() -> str:
+    """sha256 over the HIP sources and headers the library is built from (names + contents, fixed order): written
+    into every profiles/*.json by the collection tools and compared by bench.py, so counters collected from one
+    version of the kernels are never quoted for another."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, s) for s in SOURCES] + _header_paths():
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -46,6 +60,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB_PATH
     os.makedirs(OBJ_DIR, exist_ok=True)
+    # One builder at a time: bench.py --gpus N, torchrun ranks and pytest workers can all reach load() -> build() at
+    # once after a checkout; without the lock they compile into the same obj/*.o and link over a library another rank
+    # is dlopen-ing.  The link goes to a temporary name and is renamed into place (atomic on one filesystem).
+    import fcntl
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():   # somebody else built it while this process waited
+                return LIB_PATH
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     hipcc = _hipcc()
 
     def compile_one(src: str):
@@ -64,12 +93,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
     errors = [err for _, err in results if err]
     if errors:
         raise RuntimeError("hipcc failed:\n" + "\n".join(errors))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + [obj for obj, _ in results]
+    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [obj for obj, _ in results]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 

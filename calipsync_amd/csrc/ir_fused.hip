@@ -57,14 +57,65 @@ __device__ __forceinline__ int xs(int row, int col) {
   return row * RF + ((((col >> 2) ^ key)) << 2) + (col & 3);
 }
 
+// Float offset of 16-B column `col` of halo pixel (hy, hx) in the expanded tile E [IH][IW][CC].
+// P1 writes E from the MFMA C layout: eight consecutive lanes of a ds_write_b128 (one service group of a wide store)
+// hold the same channel quad of eight consecutive halo pixels, i.e. a 64-B (CC = 16) or 128-B (CC = 32) stride --
+// 4- or 8-way conflicts on the 32 store banks with a linear layout (24-46 % of all LDS cycles of these kernels were
+// conflict cycles, profiles/r2_mfma_busy.json).  So the channel quads of a pixel are XOR-permuted by a key of hx:
+// pairs of pixels share a key when a pixel is 64 B (the pair covers the two halves of the 128-B bank window), every
+// pixel has its own when it is 128 B.  P2 reads whole pixels (all quads of 16 consecutive pixels = one contiguous
+// window), so its reads stay conflict free under any permutation inside a pixel and the key costs it nothing: it
+// depends on hx only, i.e. on the tap column, not on the tap row.
+// Stride 2: the depthwise taps read every second pixel of a row, two-way conflicts on a row-major tile.  The even
+// and the odd pixels of a row are stored as two contiguous runs instead, so each tap column reads one run.
+template <int STRIDE, int CC, int IW>
+__device__ __forceinline__ int e_off(int hy, int hx, int col) {
+  constexpr int EROW = IW * CC + 4;   // IRGeom::EROW
+  constexpr int R = CC / 4;
+  int sx, key;
+  if constexpr (STRIDE == 1) {
+    sx = hx;
+    key = R == 4 ? (hx >> 1) & 3 : hx & (R - 1);
+  } else {
+    sx = (hx & 1) ? (IW + 1) / 2 + (hx >> 1) : (hx >> 1);
+    key = R == 4 ? ((hx >> 2) + 2 * (hx & 1)) & 3 : hx & (R - 1);
+  }
+  return hy * EROW + sx * CC + ((col ^ key) << 2);
+}
+
+// Halo pixel (hy, hx) that lane pixel `l15` of P1 tile `t` stands for (IRGeom: body tiles row by row, then the row
+// tails); false for the MFMA pad rows behind the last pixel.
+template <class G>
+__device__ __forceinline__ bool halo_px(int t, int l15, int& hy, int& hx) {
+  if (t < G::IH * G::BT) {
+    hy = t / G::BT;
+    hx = 16 * (t - hy * G::BT) + l15;
+    return true;
+  }
+  const int k = 16 * (t - G::IH * G::BT) + l15;
+  hy = k / G::TAIL;
+  hx = 16 * G::BT + (k - hy * G::TAIL);
+  return hy < G::IH;
+}
+
 template <int CIN, int COUT, int STRIDE, int CC>
 struct IRGeom {
   static constexpr int TH = STRIDE == 1 ? 8 : 4;
   static constexpr int OP = TH * TW;                        // output pixels per tile
   static constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
   static constexpr int HP = IH * IW;                        // halo pixels
-  static constexpr int HPP = (HP + 63) / 64 * 64;           // padded to 4 waves x 16-row tiles
-  static constexpr int MT1 = HPP / 64;                      // P1 M-tiles per wave
+  // P1 walks the halo in 16-pixel MFMA tiles that never straddle a halo row: BT "body" tiles per row (16 consecutive
+  // pixels each), then the TAIL leftover pixels of every row packed row by row into the last tile(s).  Same tile count
+  // as a plain linear walk (12 / 19), but the eight consecutive lanes that one ds_write_b128 service group takes are
+  // always eight consecutive pixels of a row (or the tails of consecutive rows), which is what e_off() makes
+  // conflict free.
+  static constexpr int BT = IW / 16, TAIL = IW - 16 * BT;
+  static constexpr int NTILE = IH * BT + (IH * TAIL + 15) / 16;
+  static constexpr int MT1 = (NTILE + 3) / 4;               // P1 M-tiles per wave
+  static constexpr int HPP = MT1 * 64;
+  // E row pitch in floats: rows are padded by 16 B so that the tails of consecutive rows (same hx, same key) fall on
+  // different banks (an unpadded row is a multiple of 64 B)
+  static constexpr int EROW = IW * CC + 4;
   static constexpr int NT1 = CC / 16;
   static constexpr int MT3 = OP / 64;                       // P3 M-tiles per wave
   static constexpr int NT3 = COUT / 16;
@@ -74,7 +125,7 @@ struct IRGeom {
   static constexpr int WBUF = wB + 2 * CC;
   // LDS carve (floats)
   static constexpr int oE = 0;
-  static constexpr int oD = oE + HP * CC;
+  static constexpr int oD = oE + IH * EROW;
   static constexpr int oW = oD + OP * CC;
   // stride 1 and CIN == COUT = the blocks with a residual connection (module/unet.py:14): their epilogue takes x
   // from a copy of the tile's centre pixels parked in LDS next to the staging area (written from the A fragments,
@@ -85,7 +136,8 @@ struct IRGeom {
   static constexpr int loop_total = oW + 2 * WBUF;
   static constexpr int total = RESC && oX + OP * CIN > loop_total ? oX + OP * CIN : loop_total;
   static_assert(OP * LDO <= total, "epilogue staging must fit in E+D+W");
-  static_assert((HP * CC) % 4 == 0 && (OP * CC) % 4 == 0 && WBUF % 4 == 0, "16-B aligned carve");
+  static_assert((IH * EROW) % 4 == 0 && (OP * CC) % 4 == 0 && WBUF % 4 == 0, "16-B aligned carve");
+  static_assert(TAIL > 0 && TAIL <= 16, "tile walk: a partial last tile per row");
   static constexpr int KG = CIN / 16;                       // k-groups of 16: one A-fragment float4 each
   static_assert(total * 4 <= 160 * 1024, "LDS budget");
   // per-thread register slots of one weight chunk in flight
@@ -131,6 +183,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
     int H, int W, int Ho, int Wo, int res, unsigned long long* __restrict__ stamps) {
   using G = IRGeom<CIN, COUT, STRIDE, CC>;
   constexpr int NCH = CE / CC;
+  static_assert(CC == 16, "e_off() keys and the E row padding are worked out for 64-B pixels");
   // diagnostic only (null in every product call; tools/experiments/ir_timeline.py): shader cycles wave 0 of
   // a workgroup spends in the prologue / P1 / P2 / P3 (each including the barrier wait that ends it) / epilogue
   unsigned long long t_mark = stamps ? __builtin_amdgcn_s_memtime() : 0, t_phase[5] = {0, 0, 0, 0, 0};
@@ -212,10 +265,10 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
   f32x4 fa[G::MT1][G::KG];
 #pragma unroll
   for (int i = 0; i < G::MT1; ++i) {
-    const int hp = 16 * (wave * G::MT1 + i) + l15;
-    const int hy = hp / G::IW, hx = hp - hy * G::IW;
+    int hy, hx;
+    const bool live = halo_px<G>(wave * G::MT1 + i, l15, hy, hx);
     const int iy = iy0 + hy, ix = ix0 + hx;
-    const bool ok = hp < G::HP && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const bool ok = live && iy >= 0 && iy < H && ix >= 0 && ix < W;
     const T* src = inb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * ld_in + 4 * q;
     if constexpr (UPS) {
       // same arithmetic as upsample2x_kernel / ATen: src = dst*(in-1)/(out-1), l1 = frac, l0 = 1-l1
@@ -263,6 +316,28 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
 #pragma unroll
     for (int n = 0; n < G::NT3; ++n) acc3[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // per-lane constants of the chunk loop: where this lane's halo pixels go in E (-1: MFMA pad row, never stored;
+  // the depthwise conv zero-pads E, so halo pixels outside the image are 0, not lrelu(b1)), and the three tap-column
+  // bases of its depthwise pixels
+  int ewr[G::MT1][G::NT1];
+  bool ein[G::MT1];
+#pragma unroll
+  for (int i = 0; i < G::MT1; ++i) {
+    int hy, hx;
+    const bool live = halo_px<G>(wave * G::MT1 + i, l15, hy, hx);
+    const int iy = iy0 + hy, ix = ix0 + hx;
+    ein[i] = !border || (iy >= 0 && iy < H && ix >= 0 && ix < W);
+#pragma unroll
+    for (int n = 0; n < G::NT1; ++n) ewr[i][n] = live ? e_off<STRIDE, CC, G::IW>(hy, hx, 4 * n + q) : -1;
+  }
+  constexpr int P2_TPP = CC / 4, P2_PPI = 256 / P2_TPP, P2_NPX = G::OP / P2_PPI;
+  static_assert(P2_PPI % TW == 0 && G::TH % P2_NPX == 0, "P2 thread map");
+  const int p2_c4 = (tid % P2_TPP) * 4, p2_px = (tid / P2_TPP) % TW, p2_py0 = ((tid / P2_TPP) / TW) * P2_NPX;
+  const float* ebk[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+    ebk[kx] = sE + e_off<STRIDE, CC, G::IW>(p2_py0 * STRIDE, p2_px * STRIDE + kx, p2_c4 >> 2);
+
 #pragma unroll 1
   for (int ch = 0; ch < NCH; ++ch) {
     const float* wb = sW + (ch & 1) * G::WBUF;
@@ -293,17 +368,10 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
       }
 #pragma unroll
       for (int i = 0; i < G::MT1; ++i) {
-        const int hp = 16 * (wave * G::MT1 + i) + l15;     // this lane's halo pixel
-        if (hp < G::HP) {
-          bool inside = true;   // the depthwise conv zero-pads E: halo pixels outside the image are 0, not lrelu(b1)
-          if (border) {
-            const int hy = hp / G::IW, hx = hp - hy * G::IW;
-            const int iy = iy0 + hy, ix = ix0 + hx;
-            inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
-          }
+        if (ewr[i][0] >= 0) {
 #pragma unroll
           for (int n = 0; n < G::NT1; ++n)
-            *reinterpret_cast<f32x4*>(sE + hp * CC + 16 * n + 4 * q) = inside ? lrelu4(acc[i][n]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(sE + ewr[i][n]) = ein[i] ? lrelu4(acc[i][n]) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
     }
@@ -316,14 +384,11 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
 
     // ---- P2: depthwise 3x3 over E -> D.  Thread = 4 channels x NPX pixels STACKED IN Y, so the
     //      (NPX-1)*STRIDE+3 tap rows are read once and shared (12 instead of 18 E reads for two
-    //      pixels); consecutive lanes still walk consecutive 16-B columns of consecutive pixels
-    //      in x, so E needs no swizzle ----
+    //      pixels); consecutive lanes walk the 16-B columns of consecutive pixels of one tap column,
+    //      one contiguous window whatever e_off() does inside a pixel ----
     {
-      constexpr int TPP = CC / 4, PPI = 256 / TPP, NPX = G::OP / PPI, NROW = (NPX - 1) * STRIDE + 3;
-      static_assert(PPI % TW == 0 && G::TH % NPX == 0, "P2 thread map");
-      const int c4 = (tid % TPP) * 4, p0 = tid / TPP;
-      const int px = p0 % TW, py0 = (p0 / TW) * NPX;
-      const float* eb = sE + ((py0 * STRIDE) * G::IW + px * STRIDE) * CC + c4;
+      constexpr int NPX = P2_NPX, NROW = (NPX - 1) * STRIDE + 3;
+      const int c4 = p2_c4, px = p2_px, py0 = p2_py0;
       const f32x4 bv = *reinterpret_cast<const f32x4*>(wb + G::wB + CC + c4);
       f32x4 a[NPX];
 #pragma unroll
@@ -335,7 +400,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
         for (int ky = 0; ky < 3; ++ky) wt[ky] = *reinterpret_cast<const f32x4*>(wb + G::wWd + (ky * 3 + kx) * CC + c4);
 #pragma unroll
         for (int r = 0; r < NROW; ++r) {
-          const f32x4 e = *reinterpret_cast<const f32x4*>(eb + (r * G::IW + kx) * CC);
+          const f32x4 e = *reinterpret_cast<const f32x4*>(ebk[kx] + r * G::EROW);
 #pragma unroll
           for (int j = 0; j < NPX; ++j) {
             const int ky = r - j * STRIDE;
@@ -384,9 +449,8 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
     if (res) {   // park x of the tile's centre pixels: [OP][CIN], straight from the A fragments
 #pragma unroll
       for (int i = 0; i < G::MT1; ++i) {
-        const int hp = 16 * (wave * G::MT1 + i) + l15;
-        const int hy = hp / G::IW, hx = hp - hy * G::IW;
-        if (hp < G::HP && hy >= 1 && hy <= G::TH && hx >= 1 && hx <= TW) {
+        int hy, hx;
+        if (halo_px<G>(wave * G::MT1 + i, l15, hy, hx) && hy >= 1 && hy <= G::TH && hx >= 1 && hx <= TW) {
           float* dst = sX + ((hy - 1) * TW + hx - 1) * CIN + 4 * q;
 #pragma unroll
           for (int g = 0; g < G::KG; ++g) *reinterpret_cast<f32x4*>(dst + 16 * g) = fa[i][g];
