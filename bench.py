@@ -37,7 +37,8 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: f32-input MFMA == f32 vector peak (155.4 measured here,
                             # profiles/r2_mfma_clock.txt)
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
-PROFILE_TAG = "r2"          # profiles/<tag>_pmc_traffic.json, <tag>_mfma_busy.json feed roofline.traffic / mfma_busy
+PROFILE_TAG = "r3"          # profiles/<tag>_pmc_traffic.json, <tag>_mfma_busy.json, <tag>_*_kernel_stats_replay.csv feed
+                            # roofline.traffic / mfma_busy / avg_kernel_us_rocprof -- only when their source_hash matches
 
 
 def parse():
@@ -63,6 +64,9 @@ def parse():
     ap.add_argument("--e2e", action="store_true",
                     help="also time the device frame loop (process_batch: crop+resize -> forward -> paste-back "
                          "blend on synthetic 1080p frames, one D2H per batch) and report it in config.e2e")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` block (N=1, default f32 run only: bf16 B=512 = configs[2], the device "
+                         "frame loop, the reference's own B=8 benchmark shape; ~20 s)")
     return ap.parse_args()
 
 
@@ -88,26 +92,73 @@ def launch_ranks(n: int) -> int:
     """``python bench.py --gpus N`` without a launcher: start N fresh child processes (one rank per GPU)
     with the torch.distributed environment, relay rank 0's JSON line, fail if any rank fails.  Nothing in
     this parent process has touched the GPU (no torch import even), so nothing is re-executed from a
-    process that initialised HIP."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if out:
-        sys.stdout.write(out)
-        sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
-        return 1
-    return 0
+    process that initialised HIP.
+
+    Watchdog: every child is polled; the first rank that exits non-zero ends the job -- the others are terminated
+    (fresh children only, never a re-exec), the parent prints that rank's stderr tail and returns its exit code, so a
+    rank that dies at import or at RCCL init costs seconds, not the collective timeout rank 0 would otherwise sit in.
+    A rendezvous port that turns out to be taken is retried on a new one."""
+    import tempfile
+    from calipsync_amd import build as _build   # plain Python, no torch / HIP
+    try:
+        _build.build()        # once, here: N ranks must not all find the library stale and rebuild it side by side
+    except Exception as exc:  # no compiler on this box: the ranks refuse a stale library themselves
+        print(f"bench.py: library not rebuilt in the launcher ({exc})", file=sys.stderr)
+    limit = float(os.environ.get("CASYNC_BENCH_TIMEOUT", "1500"))
+    for attempt in range(3):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs, outs, errs = [], [], []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            outs.append(tempfile.TemporaryFile(mode="w+"))
+            errs.append(tempfile.TemporaryFile(mode="w+"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=outs[r], stderr=errs[r], text=True))
+        t0, failed = time.monotonic(), None
+        while failed is None and any(p.poll() is None for p in procs):
+            for r, p in enumerate(procs):
+                if p.poll() not in (None, 0):
+                    failed = (r, p.returncode)
+                    break
+            if failed is None and time.monotonic() - t0 > limit:
+                failed = (-1, 124)
+            if failed is None:
+                time.sleep(0.1)
+        if failed is None:
+            failed = next(((r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0), None)
+        for p in procs:                      # stop whatever is still running (only after a failure / the time limit)
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+        def tail(f, lines=15):
+            f.seek(0)
+            return "".join(f.readlines()[-lines:])
+        if failed is None:
+            sys.stdout.write(tail(outs[0], 5))
+            sys.stdout.flush()
+            sys.stderr.write(tail(errs[0], 40))
+            return 0
+        r, rc = failed
+        err_text = tail(errs[r]) if r >= 0 else ""
+        if "address already in use" in err_text.lower() and attempt < 2:
+            print(f"bench.py: rendezvous port {port} was taken, retrying on another one", file=sys.stderr)
+            continue
+        if r < 0:
+            print(f"bench.py: ranks still running after {limit:.0f} s (CASYNC_BENCH_TIMEOUT), terminated", file=sys.stderr)
+        else:
+            print(f"bench.py: rank {r} exited with code {rc}; the other ranks were terminated.  Its stderr tail:\n{err_text}",
+                  file=sys.stderr)
+        return rc if rc else 1
+    return 1
 
 
 def cpu_baseline(sd_np, seconds: float):
@@ -144,15 +195,103 @@ def cpu_baseline(sd_np, seconds: float):
                       f"timed after one warm-up each), {spent:.1f} s of CPU work; value = the B=64 figure"}
 
 
-def load_profile_json(name):
+def load_profile_json(name, want_hash):
+    """profiles/<tag>_<name>.json if it was collected from THIS version of the kernels (its `source_hash` ==
+    sha256 of calipsync_amd/csrc, calipsync_amd.build.source_hash()), else (None, reason)."""
     path = os.path.join(REPO, "profiles", f"{PROFILE_TAG}_{name}.json")
-    return json.load(open(path)) if os.path.exists(path) else None
+    if not os.path.exists(path):
+        return None, f"profiles/{PROFILE_TAG}_{name}.json not collected yet"
+    d = json.load(open(path))
+    if d.get("source_hash") != want_hash:
+        return None, (f"profiles/{PROFILE_TAG}_{name}.json was collected from other kernel sources "
+                      f"(source_hash {str(d.get('source_hash'))[:12]} != {want_hash[:12]})")
+    return d, None
+
+
+def rocprof_avg_us(tag, kernel, want_hash):
+    """AverageNs of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of `bench.py --replay-only`
+    (profiles/<tag>_kernel_stats_replay.csv + .meta.json carrying the source hash), or (None, reason)."""
+    import csv
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    from kernel_names import short
+    path = os.path.join(REPO, "profiles", f"{tag}_kernel_stats_replay.csv")
+    meta = path.replace(".csv", ".meta.json")
+    if not (os.path.exists(path) and os.path.exists(meta)):
+        return None, f"profiles/{tag}_kernel_stats_replay.csv not collected yet"
+    if json.load(open(meta)).get("source_hash") != want_hash:
+        return None, f"profiles/{tag}_kernel_stats_replay.csv was collected from other kernel sources"
+    for r in csv.DictReader(open(path)):
+        if short(r["Name"]) == kernel:
+            return round(float(r["AverageNs"]) / 1e3, 2), None
+    return None, f"{kernel} not in profiles/{tag}_kernel_stats_replay.csv"
+
+
+def time_forward(net, x, a, warmup, steps, dev):
+    import torch
+    for _ in range(warmup):
+        out = net(x, a)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = net(x, a)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    return dt / steps
+
+
+def secondary_block(net, packed, x, a, dev, src_hash):
+    """Figures next to the headline that the driver's plain `bench.py` run would otherwise never produce
+    (N = 1 only; ~20 s): the reference's own benchmark shape (B=8 fp32), BASELINE configs[2] (bf16, B=512, with its
+    own roofline) and the device frame loop.  None of them replaces `value`."""
+    import torch
+    from calipsync_amd import arch, frame_bench
+    from calipsync_amd.unet import Model
+    sec = {}
+    work = arch.work_per_frame()
+    # the reference's own self-benchmark shape: image_infer_v1/models/unet.py:342-347 (B=8 fp32)
+    s8 = time_forward(net, x[:8], a[:8], 10, 50, dev)
+    sec["b8_fp32"] = {"value": round(8 / s8, 1), "unit": "frames/s", "ms_per_step": round(1e3 * s8, 3), "batch": 8,
+                      "dtype": "f32", "steps": 50,
+                      "mfma_frac": round(8 / s8 * work["flops"] / (MFMA_F32_PEAK_TF * 1e12), 4),
+                      "shape": "reference self-benchmark, image_infer_v1/models/unet.py:342-347"}
+    # device frame loop (SURVEY 8f rows f1-f3), median of three runs per mode
+    sec["e2e"] = frame_bench.run(net, dev, batch=x.shape[0])
+    # BASELINE configs[2]: bf16 engine, B=512 (inputs = the headline's 64 frames tiled 8x; timing is data-blind)
+    net16 = Model(6, "hubert", precision="bf16").to(dev)
+    net16.adopt_packed(packed)
+    reps = (512 + x.shape[0] - 1) // x.shape[0]
+    x16, a16 = x.repeat(reps, 1, 1, 1)[:512].contiguous(), a.repeat(reps, 1, 1, 1)[:512].contiguous()
+    s16 = time_forward(net16, x16, a16, 2, 5, dev)
+    per = {}
+    for row in net16.profile(x16, a16):
+        c = per.setdefault(row["kernel"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
+        c["ms"] += row["ms"]; c["flops"] += row["flops"]; c["bytes"] += row["bytes"]; c["n"] += 1
+    dom_name, dom = max(per.items(), key=lambda kv: kv[1]["ms"])
+    gbs, tf = dom["bytes"] / dom["ms"] / 1e6, dom["flops"] / dom["ms"] / 1e9
+    stage = arch.stagewise_bound(MFMA_BF16_PEAK_TF * 1e12, HBM_PEAK_GBS * 1e9, 2)
+    sec["bf16_b512"] = {
+        "value": round(512 / s16, 1), "unit": "frames/s", "ms_per_step": round(1e3 * s16, 3), "batch": 512, "steps": 5,
+        "dtype": "bf16 (fp32 accumulate; NOT the parity path)",
+        "roofline": {"kernel": dom_name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(gbs / HBM_PEAK_GBS, 4), "mfma_tflops": round(tf, 1),
+                     "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
+                     "share_of_step": round(dom["ms"] / sum(c["ms"] for c in per.values()), 3),
+                     "measured": "HIP events, one serialised replay of the timed run's launches"},
+        "frac_of_stagewise_bound": round(512 / s16 / stage["frames_per_s"], 4)}
+    del net16, x16, a16
+    torch.cuda.empty_cache()
+    return sec
 
 
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus))       # before torch / HIP are even imported
+
+    # test hook (tests/test_bench_launcher.py): this rank dies before it imports anything
+    if os.environ.get("CASYNC_BENCH_FAIL_RANK") == os.environ.get("RANK", ""):
+        sys.exit(3)
 
     import numpy as np  # noqa: F401
     import torch
@@ -162,7 +301,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
-    torch.set_num_threads(max(1, (os.cpu_count() or 8) // max(1, world)))   # N ranks x default threads oversubscribes
+    torch.set_num_threads(max(1, host_cores() // max(1, world)))   # the cgroup's share, split over the ranks
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path to benchmark")
     # one rank per GPU.  Rehearsal hook: on a box with fewer GPUs than ranks (the 1-GPU dev box)
@@ -179,10 +318,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = "gloo" if shared else "nccl"
+        import datetime
+        init_to = datetime.timedelta(seconds=120)   # a peer that never arrives fails this rank in two minutes
         if shared:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=init_to)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=init_to)
 
     from calipsync_amd import arch, recipe
     from calipsync_amd.unet import Model
@@ -219,15 +360,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    for _ in range(args.warmup):
-        out = net(x, a)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(1 if args.replay_only else args.steps):
-        out = net(x, a)
-    sync()
-    dt = max_over_ranks((time.perf_counter() - t0) * (args.steps if args.replay_only else 1))
-    assert torch.isfinite(out).all()
+    if args.replay_only:
+        # the mode rocprofv3 / the PMC passes are collected in: ONLY serialised replays (warm-up included), so the
+        # per-kernel statistics contain nothing but the launches the roofline block is quoted on.  `value` is then
+        # the serialised rate (no lane overlap) and the line says so.
+        for _ in range(max(1, args.warmup)):
+            net.profile(x, a)
+        sync()
+        t0 = time.perf_counter()
+        net.profile(x, a)
+        sync()
+        dt = max_over_ranks((time.perf_counter() - t0) * args.steps)
+    else:
+        for _ in range(args.warmup):
+            out = net(x, a)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = net(x, a)
+        sync()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        assert torch.isfinite(out).all()
 
     # ---- N > 1: BASELINE configs[3] beside the weak point -- a fixed 4096-frame job split over the
     #      ranks, each rank walking its contiguous shard in chunks of <= 512 frames (the per-GPU size
@@ -308,15 +461,32 @@ def main():
         # HBM-side bytes and MFMA-busy of that kernel from the committed PMC passes (tools/collect_profiles.sh
         # with --replay-only, i.e. these same launches; the counters are per launch, so they do not depend on
         # the step count).  Only for the two configurations the passes were collected on.
+        # They are quoted only when they were collected from THIS version of the kernels (source_hash), else null + why.
+        from calipsync_amd import build as _build
+        src_hash = _build.source_hash()
+        roofline["source_hash"] = src_hash
         default_cfg = (args.dtype == "f32" and B == 64) or (args.dtype == "bf16" and B == 512)
-        pmc = load_profile_json(("pmc_traffic" if args.dtype == "f32" else "pmc_traffic_bf16_b512")) if default_cfg else None
-        if pmc and dom_name in pmc["kernels"]:
-            roofline["traffic"] = pmc["kernels"][dom_name]["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = pmc["source"]
-        busy = load_profile_json(("mfma_busy" if args.dtype == "f32" else "mfma_busy_bf16_b512")) if default_cfg else None
-        if busy and dom_name in busy["kernels"]:
-            roofline["mfma_busy"] = busy["kernels"][dom_name]["mfma_busy_of_kernel_time"]
-            roofline["mfma_busy_source"] = busy["source"]
+        if default_cfg:
+            pmc, why = load_profile_json("pmc_traffic" if args.dtype == "f32" else "pmc_traffic_bf16_b512", src_hash)
+            if pmc and dom_name in pmc["kernels"]:
+                roofline["traffic"] = pmc["kernels"][dom_name]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = pmc["source"]
+            else:
+                roofline["traffic_source"] = why or f"{dom_name} not in the PMC summary"
+            busy, why = load_profile_json("mfma_busy" if args.dtype == "f32" else "mfma_busy_bf16_b512", src_hash)
+            if busy and dom_name in busy["kernels"]:
+                roofline["mfma_busy"] = busy["kernels"][dom_name]["mfma_busy_of_kernel_time"]
+                roofline["mfma_busy_source"] = busy["source"]
+            else:
+                roofline["mfma_busy"] = None
+                roofline["mfma_busy_source"] = why or f"{dom_name} not in the PMC summary"
+            avg_us, why = rocprof_avg_us(tag, dom_name, src_hash)
+            roofline["avg_kernel_us_rocprof"] = avg_us
+            if avg_us is None:
+                roofline["avg_kernel_us_rocprof_source"] = why
+            else:
+                roofline["frac_rocprof"] = round(dom["flops"] / dom["n"] / (avg_us * 1e-6) / 1e12 / mfma_peak, 4) if mfma_bound \
+                    else round(dom["bytes"] / dom["n"] / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         work = arch.work_per_frame()
         canon_bytes = work["canonical_bytes_f32"] // (1 if args.dtype == "f32" else 2)
         fps = world * B * args.steps / dt
@@ -346,7 +516,7 @@ def main():
                        "backend": {"nccl": "nccl (RCCL)", "gloo": "gloo"}.get(backend, "none (single process)"),
                        **({"rehearsal": f"{world} ranks share {n_dev} GPU(s), gloo"} if shared else {}),
                        **({"strong_scaling": strong} if strong else {})},
-            **({"replay_only": True} if args.replay_only else {}),
+            **({"replay_only": "serialised replays only: value is NOT the two-lane rate"} if args.replay_only else {}),
             "roofline": roofline,
             "whole_net": {"mfma_frac": round(per_gpu * work["flops"] / (mfma_peak * 1e12), 4),
                           "hbm_frac_canonical": round(per_gpu * canon_bytes / (HBM_PEAK_GBS * 1e9), 4),
@@ -359,6 +529,9 @@ def main():
         if args.e2e and world == 1:
             from calipsync_amd import frame_bench
             result["config"]["e2e"] = frame_bench.run(net, dev, batch=B)
+        if world == 1 and args.dtype == "f32" and not args.no_secondary and not args.replay_only and not args.global_batch:
+            from calipsync_amd import build as _build
+            result["secondary"] = secondary_block(net, packed, x, a, dev, _build.source_hash())
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd_np, args.cpu_seconds)
     if world > 1:

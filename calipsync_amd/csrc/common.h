@@ -63,6 +63,8 @@ struct CasyncOptions {
   int fuse_up = 1;           // CASYNC_FUSE_UP: bilinear upsample folded into up3/up4
   int fuse_min_hw = 32;      // CASYNC_FUSE_MIN_HW: lowest resolution the fused kernel is used at
   int fuse_q = 1;            // CASYNC_FUSE_Q: query projection as 64 extra columns of the p_1 GEMM
+  int ir_stream = 1;         // CASYNC_IR_STREAM: row-streaming fused block (ir_stream.hip) where its shapes allow, fp32
+  int ir_stream_min = 2;     // CASYNC_IR_STREAM_MIN: fewest steps per workgroup run of the streaming kernel
   int dw_lds = 1;            // CASYNC_DW_LDS: LDS-slab depthwise kernel
   int dw_lds_bytes = 32768;  // CASYNC_DW_LDS_BYTES
   int conv_im2col = 0;       // CASYNC_CONV_IM2COL: dense 3x3 via im2col + GEMM instead of the implicit GEMM
@@ -179,7 +181,14 @@ int launch_dw3x3(const void* in, const float* w, const float* bias, void* out, i
                  int wdt, int c, int stride, hipStream_t stream, int dtype = DT_F32);
 const char* dw3x3_kernel_name(int h, int wdt, int c, int stride, int dtype = DT_F32);
 bool ir_fused_supported(int cin, int cout, int stride);
-const char* ir_fused_kernel_name(int cin, int cout, int stride, int dtype = DT_F32, bool ups = false);   // as rocprofv3 prints it
+// as rocprofv3 prints it; h, w > 0: the instance launch_ir_fused / launch_ir_fused_up picks for that shape
+const char* ir_fused_kernel_name(int cin, int cout, int stride, int dtype = DT_F32, bool ups = false, int h = 0, int w = 0);
+// row-streaming variant (ir_stream.hip): fp32, stride 1, whole 8 x 16 steps
+bool ir_stream_supported(int cin, int cout, int stride, int h, int w, bool ups);
+const char* ir_stream_kernel_name(int cin, int cout, int stride, bool ups);
+int launch_ir_stream(const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const void* w1, const float* b1,
+                     const float* wd, const float* bd, const void* w2, const float* b2, void* out, int ld_out,
+                     int batch, int h, int w, int cin, int cout, int stride, int res, bool ups, hipStream_t stream);
 bool ir_fused_up_supported(int cin, int cout);
 int launch_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const void* w1,
                        const float* b1, const float* wd, const float* bd, const void* w2,

@@ -407,7 +407,7 @@ struct Plan {
     if (!extra && ir_is_fused(o, b)) {
       const double flops = 2.0 * (m_in * (double)b.cin * b.cexp() + 9.0 * m_out * b.cexp() +
                                   (double)m_out * b.cexp() * b.cout);
-      r.run((p + ".fused").c_str(), ir_fused_kernel_name(b.cin, b.cout, b.stride, dt()), flops,
+      r.run((p + ".fused").c_str(), ir_fused_kernel_name(b.cin, b.cout, b.stride, dt(), false, b.hw_in, b.hw_in), flops,
             dtype_size(dt()) * (m_in * (double)b.cin + (double)m_out * b.cout), [&] {
         return launch_ir_fused(in, ld_in, e.WG(p + ".pw1.w"), e.W(p + ".pw1.b"), e.W(p + ".dw.w"),
                                e.W(p + ".dw.b"), e.WG(p + ".pw2.w"), e.W(p + ".pw2.b"), out, ld_out, B,
@@ -576,7 +576,7 @@ struct Plan {
         // bilinear x2 folded into the fused block's input load: up(x) is never materialised
         const std::string p = b0.prefix;
         const double m = (double)B * 4 * hw * hw;
-        r.run((p + ".upfused").c_str(), ir_fused_kernel_name(b0.cin, b0.cout, 1, dt(), true),
+        r.run((p + ".upfused").c_str(), ir_fused_kernel_name(b0.cin, b0.cout, 1, dt(), true, 2 * hw, 2 * hw),
               2.0 * m * (b0.cin * b0.cexp() + 9.0 * b0.cexp() + b0.cexp() * b0.cout),
               dtype_size(dt()) * (m / 4 * c + m * c + m * b0.cout), [&] {
                 return launch_ir_fused_up(lo, c, c, cat[i], cc, e.WG(p + ".pw1.w"), e.W(p + ".pw1.b"),

@@ -1,0 +1,473 @@
+// Row-streaming fused inverted residual (fp32) for the plan's high-resolution blocks:
+//
+//   out = [x +] lrelu(W2 * lrelu(dw3x3(lrelu(W1 * x + b1)) + bd) + b2)          (reference module/unet.py:16-40)
+//
+// Same arithmetic and the same three phases per 16-channel chunk of the expanded tensor as ir_fused.hip
+// (P1 expand GEMM over the halo -> E in LDS, P2 depthwise 3x3 -> D in LDS, P3 project GEMM into registers), but a
+// workgroup does not own ONE 8x16 tile: it walks DOWN a 16-pixel-wide strip, eight output rows per step, and keeps
+// the last two rows of the expanded tile (all CE channels of them, 18 KB for CE = 128) in LDS between steps.  A step
+// then expands only its eight NEW halo rows -- 9 MFMA tiles of 16 pixels instead of the 12 a free-standing tile
+// needs (the 1-pixel halo above and below is what the tile kernel recomputes: 25 % of its expand MFMAs).
+//
+// What round 2's counters said about the tile kernel (profiles/r2_mfma_busy.json, r2_ir_ablation.txt): its loop is
+// issue bound -- on gfx950 an fp32 MFMA and a VALU instruction of ANY wave of a SIMD do not overlap, so a
+// workgroup-tile costs 32 cycles x 512 MFMAs + ~5 cycles x 1,670 VALU instructions per wave, and the three waves a
+// SIMD holds fill it completely.  A third of that VALU count was prologue / epilogue address arithmetic, masks and
+// staging.  Hence, here:
+//   * work is a linear list of steps (frame, strip, step in strip) cut into equal contiguous runs, one per
+//     workgroup, grid = what the chip holds at once; per-lane addressing is computed ONCE per workgroup:
+//     every global access of a step is   uniform 64-bit base (SALU) + per-lane constant 32-bit offset + immediate;
+//   * weights arrive by LDS-DMA (buffer_load ... lds, per-lane constant offsets, the chunk offset in an SGPR):
+//     no staging registers, no ds_write, no address VALU;
+//   * no LDS staging of the output: the MFMA C layout (lane = pixel, four consecutive channels) stores 64-B row
+//     pieces directly, the residual input is loaded in the same layout;
+//   * image borders are a wave-uniform branch (only strips / steps that touch the border compute masks).
+//
+// Shapes: fp32, stride 1 (8 x 16 output pixels per step) or stride 2 (4 x 16), H a multiple of 8, W of 16 * stride.
+// Everything else (ragged shapes, bf16) stays with ir_fused.hip.
+//
+// P1 tile slots of a wave (16 pixels each, a tile never straddles a halo row, see ir_fused.hip e_off()):
+//   slots 0 .. NB-1   body tiles of the NEW rows (rows KEEP .. IH-1), always
+//   slot NB           wave 3: the row tails (hx >= 16 * BT) of the new rows, always
+//                     waves 0, 1: the body tiles of the KEEP carried rows, wave 2: their tails -- only in a FRESH
+//                     step (the first of a run or of a strip), which has nothing carried to start from
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+#include "ir_common.h"
+
+namespace {
+
+template <int CIN, int COUT, int STRIDE>
+struct SGeom {
+  static constexpr int CC = 16, CE = 2 * CIN, NCH = CE / CC;
+  static constexpr int TH = STRIDE == 1 ? 8 : 4, OP = TH * TW;
+  static constexpr int IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
+  static constexpr int NEW = TH * STRIDE, KEEP = IH - NEW;   // E rows expanded per step / carried from the step above
+  static constexpr int BT = IW / 16, TAIL = IW - 16 * BT;
+  static constexpr int EROW = IW * CC + 4;                    // == IRGeom::EROW (e_off() assumes it)
+  static constexpr int NB = NEW * BT / 4, MT1 = NB + 1;
+  static constexpr int KG = CIN / 16, MT3 = OP / 64, NT3 = COUT / 16;
+  static constexpr int NPX = OP / 64, NROW = (NPX - 1) * STRIDE + 3;   // P2: pixels stacked in y per thread, tap rows
+  // one weight buffer: W1c [CC][CIN], W2c [COUT][CC], Wd [9][CC], b1 [CC], bd [CC]
+  static constexpr int wW1 = 0, wW2 = CC * CIN, wWd = wW2 + COUT * CC, wB = wWd + 9 * CC, WBUF = wB + 2 * CC;
+  static constexpr int oE = 0, oD = IH * EROW, oW = oD + OP * CC, oC = oW + 2 * WBUF;
+  static constexpr int CSTR = KEEP * EROW;                    // carried rows of one chunk
+  static constexpr int total = oC + NCH * CSTR;
+  // LDS-DMA pieces of one weight chunk (1 KB = one wave instruction each): W1c, W2c, then [Wd | b1 | bd]
+  static constexpr int NP1 = CC * CIN / 256, NP2 = COUT * CC / 256, NP = NP1 + NP2 + 1, NPS = (NP + 3) / 4;
+  static constexpr int occ = 160 * 1024 / (total * 4) >= 4 ? 4 : 160 * 1024 / (total * 4);
+  static_assert(NEW * BT % 4 == 0 && NEW * TAIL <= 16 && KEEP * BT <= 2 && KEEP * TAIL <= 16, "tile slots");
+  static_assert(NCH % 2 == 0 && (CC * CIN) % 256 == 0 && (COUT * CC) % 256 == 0, "weight chunk pieces");
+  static_assert(total * 4 <= 160 * 1024 && occ >= 1, "LDS budget");
+  static_assert(oD % 4 == 0 && oW % 4 == 0 && oC % 4 == 0 && CSTR % 4 == 0 && WBUF % 4 == 0, "16-B aligned carve");
+};
+
+// 16 B per lane from a buffer straight into LDS (wave-uniform LDS base + lane * 16); see gemm.hip
+__device__ __forceinline__ void dma16(const void* base, unsigned bytes, float* lds, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000),
+                                           (void __attribute__((address_space(3)))*)lds, 16, voff, soff, 0, 0);
+#endif
+}
+
+template <int CIN, int COUT, int STRIDE, bool UPS>
+__global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_stream_kernel(
+    const float* __restrict__ lo, int ld_lo, int c_lo, const float* __restrict__ in, int ld_in,
+    const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ wd,
+    const float* __restrict__ bd, const float* __restrict__ w2, const float* __restrict__ b2,
+    float* __restrict__ out, int ld_out, int B, int H, int W, int res) {
+  using G = SGeom<CIN, COUT, STRIDE>;
+  constexpr int CC = G::CC, CE = G::CE, NCH = G::NCH, EROW = G::EROW;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sE = smem + G::oE;
+  float* sD = smem + G::oD;
+  float* sW = smem + G::oW;
+  float* sC = smem + G::oC;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  const int Ho = H / STRIDE, Wo = W / STRIDE;
+  const int NSX = Wo / TW, NSY = Ho / G::TH;
+
+  // ---- this workgroup's run of steps.  Workgroups b, b + 8, ... share an XCD (round-robin dispatch): give every
+  //      XCD one contiguous eighth of the list, so strips that share halo columns share an L2 (speed only).
+  const long long U = (long long)B * NSX * NSY;
+  int g = blockIdx.x;
+  const int Gn = gridDim.x;
+  if ((Gn & 7) == 0) g = (g & 7) * (Gn >> 3) + (g >> 3);
+  const long long u0 = U * g / Gn, u1 = U * (g + 1) / Gn;
+  if (u0 >= u1) return;
+  int sy = (int)(u0 % NSY);
+  int sx = (int)((u0 / NSY) % NSX);
+  int bi = (int)(u0 / ((long long)NSY * NSX));
+
+  // ================= per-lane constants (once per workgroup) =================
+  // P1 slots: halo pixel (ry, hx) of this lane in E-tile coordinates; slot NB depends on the wave (see header)
+  int s_ry[G::MT1], s_hx[G::MT1];
+  bool x_live;   // slot NB holds a real pixel for this lane
+#pragma unroll
+  for (int i = 0; i < G::NB; ++i) {
+    const int bt = wave + 4 * i;                       // body tile of the new rows
+    s_ry[i] = G::KEEP + bt / G::BT;
+    s_hx[i] = 16 * (bt % G::BT) + l15;
+  }
+  if (wave == 3) {
+    x_live = l15 < G::NEW * G::TAIL;
+    s_ry[G::NB] = G::KEEP + l15 / G::TAIL;
+    s_hx[G::NB] = 16 * G::BT + l15 % G::TAIL;
+  } else if (wave == 2) {
+    x_live = l15 < G::KEEP * G::TAIL;
+    s_ry[G::NB] = l15 / G::TAIL;
+    s_hx[G::NB] = 16 * G::BT + l15 % G::TAIL;
+  } else {
+    x_live = wave < G::KEEP * G::BT;
+    s_ry[G::NB] = wave / G::BT;
+    s_hx[G::NB] = 16 * (wave % G::BT) + l15;
+  }
+  if (!x_live) s_ry[G::NB] = 0, s_hx[G::NB] = 0;
+  int voffA[G::MT1], ewr[G::MT1];      // float offsets: input pixel relative to the step's halo origin, E slot
+#pragma unroll
+  for (int i = 0; i < G::MT1; ++i) {
+    voffA[i] = (s_ry[i] * W + s_hx[i]) * ld_in + 4 * q;
+    ewr[i] = e_off<STRIDE, CC, G::IW>(s_ry[i], s_hx[i], q);
+  }
+  // W1 fragment offsets (the MFMA A operand: row = channel l15 of the chunk, 16-B column 4g + q, swizzled)
+  int w1fr[G::KG];
+#pragma unroll
+  for (int g4 = 0; g4 < G::KG; ++g4) w1fr[g4] = G::wW1 + xs<CIN>(l15, 16 * g4 + 4 * q);
+  const int w2fr = G::wW2 + xs<CC>(l15, 4 * q);          // + 16 * n rows = + 256 * n floats (key is n-independent)
+  // P2: thread = channel quad x NPX pixels stacked in y
+  const int p2_c4 = (tid & 3) * 4, p2_px = (tid >> 2) & 15, p2_py0 = wave * G::NPX;
+  int ebk[3], dwr[G::NPX];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) ebk[kx] = e_off<STRIDE, CC, G::IW>(p2_py0 * STRIDE, p2_px * STRIDE + kx, p2_c4 >> 2);
+#pragma unroll
+  for (int j = 0; j < G::NPX; ++j) dwr[j] = xs<CC>((p2_py0 + j) * TW + p2_px, p2_c4);
+  // P3 / epilogue: tile t = wave * MT3 + i is output row t of the step, lane pixel l15, channels 16n + 4q ..
+  int dfr[G::MT3], voffO[G::MT3], voffX[G::MT3];
+#pragma unroll
+  for (int i = 0; i < G::MT3; ++i) {
+    const int py = wave * G::MT3 + i;
+    dfr[i] = xs<CC>(16 * py + l15, 4 * q);
+    voffO[i] = (py * Wo + l15) * ld_out + 4 * q;
+    voffX[i] = ((py + 1) * W + l15 + 1) * ld_in + 4 * q;    // residual (stride 1): the block input at the output pixel
+  }
+  // weight pieces of this wave: piece p = 4 * s + wave
+  int voffW[G::NPS];
+#pragma unroll
+  for (int s = 0; s < G::NPS; ++s) {
+    const int p = 4 * s + wave;
+    if (p < G::NP1) {                 // rows of W1c: LDS float offset f -> (row, 16-B slot); source column = slot ^ key
+      const int f = p * 256 + lane * 4, row = f / CIN, slot = (f - row * CIN) >> 2;
+      const int src_col4 = (xs<CIN>(row, 4 * slot) - row * CIN) >> 2;    // xs is an involution on the slot index
+      voffW[s] = (row * CIN + 4 * src_col4) * 4;
+    } else if (p < G::NP1 + G::NP2) {
+      const int f = (p - G::NP1) * 256 + lane * 4, row = f / CC, slot = (f - row * CC) >> 2;
+      const int src_col4 = (xs<CC>(row, 4 * slot) - row * CC) >> 2;
+      voffW[s] = (row * CE + 4 * src_col4) * 4;
+    } else {
+      voffW[s] = 0;
+    }
+  }
+  // [Wd | b1 | bd] piece: 11 rows of 16 floats, lane -> (row t, quad)
+  const int wd_t = lane >> 2;
+  const float* wd_src = (wd_t < 9 ? wd + (size_t)wd_t * CE : (wd_t == 9 ? b1 : bd)) + (lane & 3) * 4;
+  auto issue_weights = [&](int ch, int buf) {   // chunk ch -> weight buffer buf (all four waves, 1-2 pieces each)
+    float* wb = sW + buf * G::WBUF;
+#pragma unroll
+    for (int s = 0; s < G::NPS; ++s) {
+      const int p = 4 * s + wave;
+      if (p < G::NP1) {
+        dma16(w1, (unsigned)CE * CIN * 4, wb + G::wW1 + p * 256, voffW[s], ch * CC * CIN * 4);
+      } else if (p < G::NP1 + G::NP2) {
+        dma16(w2, (unsigned)COUT * CE * 4, wb + G::wW2 + (p - G::NP1) * 256, voffW[s], ch * CC * 4);
+      } else if (p == G::NP1 + G::NP2) {
+        if (lane < 44)
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(wd_src + ch * CC),
+                                           (void __attribute__((address_space(3)))*)(wb + G::wWd), 16, 0, 0);
+      }
+    }
+  };
+
+  // carried rows: wave 0 copies E rows NEW .. IH-1 of a chunk into the chunk's carry slot (this lane's pieces)
+  constexpr int CPL = (G::CSTR / 4 + 63) / 64;
+  // UPS: per-lane x taps of the bilinear x2 upsample (align_corners=True) are step-invariant
+  const int Hl = H >> 1, Wl = W >> 1;
+  const float ups_sy = UPS ? (float)(Hl - 1) / (float)(H - 1) : 0.f, ups_sx = UPS ? (float)(Wl - 1) / (float)(W - 1) : 0.f;
+
+  issue_weights(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // the first chunk's weights have landed for everyone (later steps: issued and awaited one chunk ahead)
+  bool first = true;
+
+#pragma unroll 1
+  for (long long u = u0; u < u1; ++u) {
+    const bool fresh = first || sy == 0;
+    first = false;
+    const bool more = u + 1 < u1;
+    const int y0 = sy * G::TH, x0 = sx * TW;                   // output origin of the step
+    const int iy0 = y0 * STRIDE - 1, ix0 = x0 * STRIDE - 1;    // input pixel of halo (0, 0)
+    const bool border = iy0 < 0 || ix0 < 0 || iy0 + G::IH > H || ix0 + G::IW > W;
+    const bool has_x = fresh || wave == 3;
+    const float* inb = in + ((size_t)bi * H * W + (long long)iy0 * W + ix0) * ld_in;   // may point before the frame: only
+                                                                                        // dereferenced at live pixels
+    float* outb = out + ((size_t)bi * Ho * Wo + (size_t)y0 * Wo + x0) * ld_out;
+
+    // ---- A fragments of this step's new halo rows: HBM -> registers ----
+    f32x4 fa[G::MT1][G::KG];
+    bool okm[G::MT1];
+#pragma unroll
+    for (int i = 0; i < G::MT1; ++i) {
+      const bool slot_on = i < G::NB || has_x;
+      bool ok = i < G::NB || x_live;
+      if (border) {
+        const int iy = iy0 + s_ry[i], ix = ix0 + s_hx[i];
+        ok = ok && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      }
+      okm[i] = ok;
+      if (!slot_on) continue;      // wave-uniform
+      if constexpr (UPS) {
+        // same arithmetic as upsample2x_kernel / ATen: src = dst*(in-1)/(out-1), l1 = frac, l0 = 1-l1
+        const int iy = ok ? iy0 + s_ry[i] : 0, ix = ok ? ix0 + s_hx[i] : 0;
+        const float fy = ups_sy * iy, fx = ups_sx * ix;
+        const int yl0 = (int)fy, xl0 = (int)fx;
+        const int yl1 = yl0 + (yl0 < Hl - 1), xl1 = xl0 + (xl0 < Wl - 1);
+        const float ly1 = fy - yl0, lx1 = fx - xl0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float* lb = lo + (size_t)bi * Hl * Wl * ld_lo + 4 * q;
+        const float* p00 = lb + ((size_t)yl0 * Wl + xl0) * ld_lo;
+        const float* p01 = lb + ((size_t)yl0 * Wl + xl1) * ld_lo;
+        const float* p10 = lb + ((size_t)yl1 * Wl + xl0) * ld_lo;
+        const float* p11 = lb + ((size_t)yl1 * Wl + xl1) * ld_lo;
+#pragma unroll
+        for (int g4 = 0; g4 < G::KG; ++g4) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (ok) {
+            if (16 * g4 < c_lo) {
+              const f32x4 v00 = *reinterpret_cast<const f32x4*>(p00 + 16 * g4);
+              const f32x4 v01 = *reinterpret_cast<const f32x4*>(p01 + 16 * g4);
+              const f32x4 v10 = *reinterpret_cast<const f32x4*>(p10 + 16 * g4);
+              const f32x4 v11 = *reinterpret_cast<const f32x4*>(p11 + 16 * g4);
+              v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+            } else {
+              v = *reinterpret_cast<const f32x4*>(inb + (unsigned)voffA[i] + 16 * g4);
+            }
+          }
+          fa[i][g4] = v;
+        }
+      } else {
+        if (border) {
+#pragma unroll
+          for (int g4 = 0; g4 < G::KG; ++g4)
+            fa[i][g4] = ok ? *reinterpret_cast<const f32x4*>(inb + (unsigned)voffA[i] + 16 * g4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else if (i < G::NB) {
+#pragma unroll
+          for (int g4 = 0; g4 < G::KG; ++g4) fa[i][g4] = *reinterpret_cast<const f32x4*>(inb + (unsigned)voffA[i] + 16 * g4);
+        } else {
+#pragma unroll
+          for (int g4 = 0; g4 < G::KG; ++g4)
+            fa[i][g4] = x_live ? *reinterpret_cast<const f32x4*>(inb + (unsigned)voffA[i] + 16 * g4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+
+    f32x4 acc3[G::MT3][G::NT3];
+#pragma unroll
+    for (int i = 0; i < G::MT3; ++i)
+#pragma unroll
+      for (int n = 0; n < G::NT3; ++n) acc3[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 xres[G::MT3][G::NT3];
+
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+      const float* wb = sW + (ch & 1) * G::WBUF;
+      // ---- P1: expand GEMM over the new halo rows (weights = MFMA A operand, pixels = B operand: a lane ends up
+      //      with 4 consecutive channels of one pixel -> one 16-B LDS store per tile).  Bias = initial accumulator.
+      {
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(wb + G::wB + 4 * q);
+        auto p1 = [&](auto ns_c) {
+          constexpr int NS = decltype(ns_c)::value;
+          f32x4 acc[NS];
+#pragma unroll
+          for (int i = 0; i < NS; ++i) acc[i] = bias;
+#pragma unroll
+          for (int g4 = 0; g4 < G::KG; ++g4) {
+            const f32x4 fb = *reinterpret_cast<const f32x4*>(wb + w1fr[g4]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int i = 0; i < NS; ++i) acc[i] = mfma16(fb[s], fa[i][g4][s], acc[i]);
+          }
+          if (border) {   // the depthwise conv zero-pads E: halo pixels outside the image are 0, not lrelu(b1)
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+              if (i < G::NB || x_live)
+                *reinterpret_cast<f32x4*>(sE + ewr[i]) = okm[i] ? lrelu4(acc[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+          } else {
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+              if (i < G::NB || x_live) *reinterpret_cast<f32x4*>(sE + ewr[i]) = lrelu4(acc[i]);
+          }
+        };
+        if (has_x) p1(std::integral_constant<int, G::MT1>{});
+        else p1(std::integral_constant<int, G::NB>{});
+      }
+      __syncthreads();  // E complete; every wave is done with the previous chunk's P3 (and its weight buffer)
+      // the next chunk's weights (the next step's first chunk behind the last one) into the other buffer
+      if (ch + 1 < NCH) issue_weights(ch + 1, (ch + 1) & 1);
+      else if (more) issue_weights(0, 0);
+      if (res && ch == NCH - 1) {      // residual input in the accumulator layout, in flight under P2 / P3
+#pragma unroll
+        for (int i = 0; i < G::MT3; ++i)
+#pragma unroll
+          for (int n = 0; n < G::NT3; ++n) xres[i][n] = *reinterpret_cast<const f32x4*>(inb + (unsigned)voffX[i] + 16 * n);
+      }
+
+      // ---- P2: depthwise 3x3 over E -> D.  Rows the step did not expand (wave 0, rows < KEEP) come from the
+      //      chunk's carry slot; afterwards wave 0 refreshes the slot with this step's last rows.
+      {
+        const bool use_carry = wave == 0 && !fresh;
+        const int cdelta = G::oC + ch * G::CSTR - G::oE;
+        const float* wq = wb + p2_c4;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(wq + G::wB + CC);
+        f32x4 a[G::NPX];
+#pragma unroll
+        for (int j = 0; j < G::NPX; ++j) a[j] = bv;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {   // one tap column at a time: only three weight vectors live
+          f32x4 wt[3];
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) wt[ky] = *reinterpret_cast<const f32x4*>(wq + G::wWd + (ky * 3 + kx) * CC);
+          const float* e0 = sE + ebk[kx];
+          const float* c0 = use_carry ? e0 + cdelta : e0;
+#pragma unroll
+          for (int r = 0; r < G::NROW; ++r) {
+            const f32x4 e = *reinterpret_cast<const f32x4*>((r < G::KEEP ? c0 : e0) + r * EROW);
+#pragma unroll
+            for (int j = 0; j < G::NPX; ++j) {
+              const int ky = r - j * STRIDE;
+              if (ky >= 0 && ky < 3) a[j] += e * wt[ky];
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < G::NPX; ++j) *reinterpret_cast<f32x4*>(sD + dwr[j]) = lrelu4(a[j]);
+        if (wave == 0 && sy + 1 < NSY) {   // (the reads above are done: LDS operations of a wave complete in order)
+#pragma unroll
+          for (int r = 0; r < CPL; ++r) {
+            const int idx = lane + 64 * r;
+            if (CPL * 64 == G::CSTR / 4 || idx < G::CSTR / 4)
+              *reinterpret_cast<f32x4*>(sC + ch * G::CSTR + 4 * idx) =
+                  *reinterpret_cast<const f32x4*>(sE + G::NEW * EROW + 4 * idx);
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the next weights has landed
+      __syncthreads();  // D complete, the next weights visible
+
+      // ---- P3: project GEMM, acc3[pixel][cout] += D[pixel][CC] x W2c^T (W2c = A operand, pixels = B operand) ----
+      {
+        f32x4 fd[G::MT3], fw[G::NT3];
+#pragma unroll
+        for (int i = 0; i < G::MT3; ++i) fd[i] = *reinterpret_cast<const f32x4*>(sD + dfr[i]);
+#pragma unroll
+        for (int n = 0; n < G::NT3; ++n) fw[n] = *reinterpret_cast<const f32x4*>(wb + w2fr + 256 * n);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < G::MT3; ++i)
+#pragma unroll
+            for (int n = 0; n < G::NT3; ++n) acc3[i][n] = mfma16(fw[n][s], fd[i][s], acc3[i][n]);
+      }
+      // no barrier here: the next P1 writes E only, which nobody reads until after its barrier
+    }
+
+    // ---- epilogue: + b2, LReLU (+ x), straight from the accumulator layout: 64-B row pieces per pixel ----
+#pragma unroll
+    for (int n = 0; n < G::NT3; ++n) {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(b2 + 16 * n + 4 * q);
+#pragma unroll
+      for (int i = 0; i < G::MT3; ++i) {
+        f32x4 v = lrelu4(acc3[i][n] + bias);
+        if (res) v += xres[i][n];
+        *reinterpret_cast<f32x4*>(outb + (unsigned)voffO[i] + 16 * n) = v;
+      }
+    }
+
+    if (++sy == NSY) {
+      sy = 0;
+      if (++sx == NSX) sx = 0, ++bi;
+    }
+  }
+}
+
+template <int CIN, int COUT, int STRIDE, bool UPS>
+int launch_stream(const float* lo, int ld_lo, int c_lo, const float* in, int ld_in, const float* w1, const float* b1,
+                  const float* wd, const float* bd, const float* w2, const float* b2, float* out, int ld_out, int batch,
+                  int h, int w, int res, hipStream_t stream) {
+  using G = SGeom<CIN, COUT, STRIDE>;
+  constexpr size_t lds = (size_t)G::total * sizeof(float);
+  auto kern = ir_stream_kernel<CIN, COUT, STRIDE, UPS>;
+  static unsigned long long attr_once = 0;
+  if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)lds)) return st;
+  const long long steps = (long long)batch * (w / STRIDE / TW) * (h / STRIDE / G::TH);
+  // one run per workgroup slot of the chip; at least ir_stream_min steps per run (a run's first step has no carried
+  // rows and expands all IH of them)
+  const int min_steps = casync_opts().ir_stream_min > 0 ? casync_opts().ir_stream_min : 1;
+  long long grid = 256ll * G::occ;
+  if (grid * min_steps > steps) grid = (steps + min_steps - 1) / min_steps;
+  if (grid >= 16) grid &= ~7ll;      // whole multiples of the eight XCDs (the run -> XCD remap needs it)
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2,
+                     out, ld_out, batch, h, w, res);
+  CASYNC_CHECK_HIP(hipGetLastError());
+  return CASYNC_OK;
+}
+
+}  // namespace
+
+// Shapes the streaming kernel takes (everything else: ir_fused.hip): fp32, whole steps, and enough of them.
+bool ir_stream_supported(int cin, int cout, int stride, int h, int w, bool ups) {
+  if (h % 8 || w % (16 * stride) || h < 40) return false;
+  if (stride != 1) return false;
+  if (ups) return cout == 32 && (cin == 64 || cin == 128);
+  return (cin == 32 && cout == 32) || (cin == 64 && cout == 32) || (cin == 128 && cout == 32) || (cin == 64 && cout == 64);
+}
+
+const char* ir_stream_kernel_name(int cin, int cout, int stride, bool ups) {
+  static thread_local char buf[64];
+  snprintf(buf, sizeof(buf), "ir_stream_kernel<%d, %d, %d, %s>", cin, cout, stride, ups ? "true" : "false");
+  return buf;
+}
+
+int launch_ir_stream(const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const void* w1, const float* b1,
+                     const float* wd, const float* bd, const void* w2, const float* b2, void* out, int ld_out,
+                     int batch, int h, int w, int cin, int cout, int stride, int res, bool ups, hipStream_t stream) {
+  CASYNC_REQUIRE(in && w1 && b1 && wd && bd && w2 && b2 && out && (!ups || lo), "ir_stream: null pointer");
+  CASYNC_REQUIRE(ir_stream_supported(cin, cout, stride, h, w, ups), "ir_stream: no instance for cin=%d cout=%d stride=%d %dx%d",
+                 cin, cout, stride, h, w);
+  CASYNC_REQUIRE(batch > 0 && ld_in >= cin && ld_in % 4 == 0 && ld_out >= cout && ld_out % 4 == 0, "ir_stream: bad ld");
+  CASYNC_REQUIRE(!res || (stride == 1 && cin == cout), "ir_stream: residual needs stride 1 and cin == cout");
+  CASYNC_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)lo % 16) == 0 &&
+                     ((uintptr_t)w1 % 16) == 0 && ((uintptr_t)w2 % 16) == 0 && ((uintptr_t)wd % 16) == 0 &&
+                     ((uintptr_t)b1 % 16) == 0 && ((uintptr_t)bd % 16) == 0 && ((uintptr_t)b2 % 16) == 0,
+                 "ir_stream: alignment");
+  // per-lane offsets are 32-bit floats-in-frame: one frame of the widest buffer must stay below 2^31 bytes
+  CASYNC_REQUIRE((long long)h * w * ld_in * 4 < (1ll << 31) && (long long)h * w * ld_out * 4 < (1ll << 31), "ir_stream: frame too large");
+  if (ups) CASYNC_REQUIRE(c_lo > 0 && c_lo < cin && c_lo % 16 == 0 && ld_lo >= c_lo && ld_lo % 4 == 0, "ir_stream: bad c_lo/ld_lo");
+#define S_CASE(CI, CO, S, U)                                                                                      \
+  if (cin == CI && cout == CO && stride == S && ups == U)                                                         \
+    return launch_stream<CI, CO, S, U>((const float*)lo, ld_lo, c_lo, (const float*)in, ld_in, (const float*)w1, b1, wd, bd, \
+                                       (const float*)w2, b2, (float*)out, ld_out, batch, h, w, res, stream);
+  S_CASE(64, 32, 1, true)     // up4.ir0
+  S_CASE(128, 32, 1, true)    // up3.ir0
+  S_CASE(64, 32, 1, false)
+  S_CASE(128, 32, 1, false)
+  S_CASE(32, 32, 1, false)    // up4.ir1, up3.ir1
+  S_CASE(64, 64, 1, false)    // down1.ir1, up2.ir1
+#undef S_CASE
+  casync_set_error("ir_stream: no instance for cin=%d cout=%d stride=%d", cin, cout, stride);
+  return CASYNC_ERR_ARG;
+}

@@ -33,6 +33,8 @@ const OptField kFields[] = {
     {"fuse_up", &CasyncOptions::fuse_up},
     {"fuse_min_hw", &CasyncOptions::fuse_min_hw},
     {"fuse_q", &CasyncOptions::fuse_q},
+    {"ir_stream", &CasyncOptions::ir_stream},
+    {"ir_stream_min", &CasyncOptions::ir_stream_min},
     {"dw_lds", &CasyncOptions::dw_lds},
     {"dw_lds_bytes", &CasyncOptions::dw_lds_bytes},
     {"conv_im2col", &CasyncOptions::conv_im2col},

@@ -341,6 +341,62 @@ def test_ir_fused_with_upsample(lib, recipe_sd, prefix, cin, h):
     assert rel_err(nchw(out), ref) < 5e-6
 
 
+STREAM_CASES = [  # (state_dict prefix, cin, cout, res, ups, h, w, batch)
+    ("up4.conv.double_conv.0", 64, 32, False, False, 48, 32, 3),
+    ("up4.conv.double_conv.0", 64, 32, False, True, 48, 32, 3),
+    ("up3.conv.double_conv.0", 128, 32, False, False, 40, 48, 2),
+    ("up3.conv.double_conv.0", 128, 32, False, True, 64, 32, 2),
+    ("up4.conv.double_conv.1", 32, 32, True, False, 56, 48, 3),
+    ("down1.maxpool_conv.0.double_conv.1", 64, 64, True, False, 40, 32, 3),
+]
+
+
+@pytest.mark.parametrize("min_steps", [1, 2, 5, 1000])
+@pytest.mark.parametrize("prefix,cin,cout,res,ups,h,w,b", STREAM_CASES)
+def test_ir_stream_equals_tile_kernel(lib, recipe_sd, prefix, cin, cout, res, ups, h, w, b, min_steps):
+    """The row-streaming kernel (ir_stream.hip) against the tile kernel (ir_fused.hip, ir_stream=0) and the oracle:
+    same products in the same order, so the two kernels agree BIT FOR BIT -- for every way of cutting the step list
+    into workgroup runs (min_steps 1: every step starts fresh, 2 / 5: runs carry rows, cross strips and frames,
+    1000: one workgroup walks everything), with strided channel-slice operands."""
+    from oracle import unet_oracle
+    sd = unet_oracle.to_torch(recipe_sd)
+    f = pack.fold(recipe_sd)
+    g = torch.Generator().manual_seed(h * 11 + cin + int(ups))
+    T = lambda k: torch.from_numpy(f[f"{prefix}.{k}"].astype(np.float32)).contiguous().to(dev())
+    w1, b1, wd, bd, w2, b2 = T("pw1.w"), T("pw1.b"), T("dw.w"), T("dw.b"), T("pw2.w"), T("pw2.b")
+    ld_in, ld_out = cin + 16, cout + 16
+    if ups:
+        c_lo = cin // 2
+        lo = torch.randn(b, c_lo, h // 2, w // 2, generator=g)
+        skip = torch.randn(b, cin - c_lo, h, w, generator=g)
+        x = torch.cat([F.interpolate(lo, scale_factor=2, mode="bilinear", align_corners=True), skip], 1)
+        xin = torch.full((b, h, w, ld_in), 77.0)                 # the upsampled half is never materialised
+        xin[..., 16 + c_lo:] = skip.permute(0, 2, 3, 1)
+        lod = nhwc(lo)
+    else:
+        x = torch.randn(b, cin, h, w, generator=g)
+        xin = torch.full((b, h, w, ld_in), 3.0)
+        xin[..., 16:] = x.permute(0, 2, 3, 1)
+    ref = unet_oracle.inverted_residual(sd, prefix, x, 1, res)
+    xin = xin.to(dev())
+    outs = []
+    for use_stream in (1, 0):
+        out = torch.full((b, h, w, ld_out), -5.0, device=dev())
+        with options(ir_stream=use_stream, ir_stream_min=min_steps):
+            if ups:
+                ok(lib.casync_op_ir_fused_up(ptr(lod), c_lo, c_lo, xin.data_ptr() + 16 * 4, ld_in, ptr(w1), ptr(b1), ptr(wd),
+                                             ptr(bd), ptr(w2), ptr(b2), out.data_ptr() + 16 * 4, ld_out, b, h, w, cin, cout,
+                                             stream()))
+            else:
+                ok(lib.casync_op_ir_fused(xin.data_ptr() + 16 * 4, ld_in, ptr(w1), ptr(b1), ptr(wd), ptr(bd), ptr(w2), ptr(b2),
+                                          out.data_ptr() + 16 * 4, ld_out, b, h, w, cin, cout, 1, int(res), stream()))
+        o = out.cpu()
+        assert (o[..., :16] == -5).all()
+        outs.append(o[..., 16:].permute(0, 3, 1, 2))
+        assert rel_err(outs[-1], ref) < 5e-6, (use_stream, rel_err(outs[-1], ref))
+    assert torch.equal(outs[0], outs[1])
+
+
 # ------------------------------------------------------------------ bf16 storage (BASELINE configs[2])
 @pytest.fixture()
 def bf16_ops(lib):
