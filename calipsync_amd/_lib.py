@@ -72,7 +72,7 @@ _PROTOS = {
     "casync_op_crop_to_input": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.c_void_p]),
     "casync_op_pred_to_u8": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_void_p]),
     "casync_frame_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, c_f32p, C.c_void_p]),
-    "casync_frame_paste_back": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_f32p, C.c_void_p, c_f32p, C.c_int,
+    "casync_frame_paste_back": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_f32p, C.c_int,
                                           C.c_int, C.c_int, C.c_int, c_i64, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "casync_op_nchw_to_nhwc": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -81,7 +81,7 @@ _PROTOS = {
 }
 
 EXPORTS = tuple(_PROTOS)
-ABI_VERSION = 2          # == CASYNC_ABI_VERSION of include/casync_hip.h this file was written against
+ABI_VERSION = 3          # == CASYNC_ABI_VERSION of include/casync_hip.h this file was written against
 
 
 def lib_path() -> str:

@@ -35,6 +35,29 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, f32x4 v) {
 
 __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : v * CASYNC_LRELU_SLOPE; }
 
+// Bilinear x2 upsample with align_corners=True (module/unet.py:86-91), the arithmetic of ATen's upsample_bilinear2d
+// evaluated exactly as written: src = dst * (in-1)/(out-1), l1 = frac, l0 = 1 - l1, taps combined as
+// l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11).  No fma contraction, so every kernel that folds the upsample
+// (upsample2x_kernel, ir_fused, ir_stream) produces the SAME bits -- what the compiler fuses would otherwise differ
+// from one surrounding code to the next.
+struct UpsTap { int i0, i1; float l0, l1; };
+__device__ __forceinline__ UpsTap ups_tap(float scale, int dst, int n_in) {
+#pragma clang fp contract(off)
+  const float f = scale * (float)dst;
+  UpsTap t;
+  t.i0 = (int)f;
+  t.i1 = t.i0 + (t.i0 < n_in - 1);
+  t.l1 = f - (float)t.i0;
+  t.l0 = 1.f - t.l1;
+  return t;
+}
+__device__ __forceinline__ f32x4 ups_lerp(const UpsTap& ty, const UpsTap& tx, f32x4 v00, f32x4 v01, f32x4 v10, f32x4 v11) {
+#pragma clang fp contract(off)
+  const f32x4 top = tx.l0 * v00 + tx.l1 * v01;
+  const f32x4 bot = tx.l0 * v10 + tx.l1 * v11;
+  return ty.l0 * top + ty.l1 * bot;
+}
+
 // thread-local error text behind casync_last_error()
 void casync_set_error(const char* fmt, ...);
 

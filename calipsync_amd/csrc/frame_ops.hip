@@ -23,7 +23,8 @@
 namespace {
 
 constexpr int GEOM = 12;   // int32 words per frame: see casync_hip.h (casync_frame_geom)
-enum { G_REG_OFF = 0, G_H, G_W, G_WIDTH, G_VALID, G_SYNTH_OFF, G_MASK_OFF, G_FMASK_OFF, G_FMASK_H, G_FMASK_W };
+enum { G_REG_OFF = 0, G_H, G_W, G_WIDTH, G_VALID, G_SYNTH_OFF, G_MASK_OFF, G_FMASK_KIND, G_FMASK_H, G_FMASK_W, G_FMASK_LO, G_FMASK_HI };
+enum { FMASK_NONE = -1, FMASK_F32 = 0, FMASK_U8 = 1 };   // the optional frame mask: float32 in [0,1], or uint8 (= value / 255)
 constexpr int NPTS = 33;
 constexpr int XY_SHIFT = 16;
 constexpr long long XY_ONE = 1ll << XY_SHIFT;
@@ -282,7 +283,6 @@ __global__ __launch_bounds__(256) void frame_blend_kernel(const unsigned char* _
                                                           const int* __restrict__ geom,
                                                           const unsigned char* __restrict__ synth,
                                                           const unsigned char* __restrict__ mask,
-                                                          const float* __restrict__ fmasks,
                                                           unsigned char* __restrict__ out) {
   const int b = blockIdx.y;
   const int* g = geom + b * GEOM;
@@ -296,22 +296,28 @@ __global__ __launch_bounds__(256) void frame_blend_kernel(const unsigned char* _
     return;
   }
   double comb = (double)mask[g[G_MASK_OFF] + p] / 255.0;            // final_face_mask / 255.0
-  if (g[G_FMASK_OFF] >= 0) {
-    // resized_mask = cv2.resize(mask, (w, h)) on float32 (float tables, S0*b0 + S1*b1)
+  if (g[G_FMASK_KIND] != FMASK_NONE) {
+    // resized_mask = cv2.resize(mask, (w, h)) on float32 (float tables, S0*b0 + S1*b1).  The mask is the frame's
+    // own allocation (absolute address in the geometry record); a uint8 mask stands for value / 255 in float32,
+    // exactly what infer_api.py:68-70 computes on the host (imread(...).astype(np.float32) / 255.0).
     const int mh = g[G_FMASK_H], mw = g[G_FMASK_W];
-    const float* fm = fmasks + g[G_FMASK_OFF];
+    const unsigned long long addr = (unsigned long long)(unsigned)g[G_FMASK_LO] | ((unsigned long long)(unsigned)g[G_FMASK_HI] << 32);
+    const bool u8 = g[G_FMASK_KIND] == FMASK_U8;
+    const float* fmf = reinterpret_cast<const float*>(addr);
+    const unsigned char* fmu = reinterpret_cast<const unsigned char*>(addr);
+    auto fm = [&](size_t i) { return u8 ? __fdiv_rn((float)fmu[i], 255.0f) : fmf[i]; };
     const int y = (int)(p / w), x = (int)(p - (long long)y * w);
     float rm;
     if (mh == h && mw == w) {
-      rm = fm[(size_t)y * mw + x];
+      rm = fm((size_t)y * mw + x);
     } else if (mw == 2 * w && mh == 2 * h) {
-      rm = (fm[(size_t)(2 * y) * mw + 2 * x] + fm[(size_t)(2 * y) * mw + 2 * x + 1] + fm[(size_t)(2 * y + 1) * mw + 2 * x] +
-            fm[(size_t)(2 * y + 1) * mw + 2 * x + 1]) * 0.25f;
+      rm = (fm((size_t)(2 * y) * mw + 2 * x) + fm((size_t)(2 * y) * mw + 2 * x + 1) + fm((size_t)(2 * y + 1) * mw + 2 * x) +
+            fm((size_t)(2 * y + 1) * mw + 2 * x + 1)) * 0.25f;
     } else {
       const Tap tx = linear_tap_x(x, mw, w), ty = linear_tap_y(y, mh, h);
       const float a0 = 1.f - tx.f, a1 = tx.f, b0 = 1.f - ty.f, b1 = ty.f;
-      const float h0 = fm[(size_t)ty.s0 * mw + tx.s0] * a0 + fm[(size_t)ty.s0 * mw + tx.s1] * a1;
-      const float h1 = fm[(size_t)ty.s1 * mw + tx.s0] * a0 + fm[(size_t)ty.s1 * mw + tx.s1] * a1;
+      const float h0 = fm((size_t)ty.s0 * mw + tx.s0) * a0 + fm((size_t)ty.s0 * mw + tx.s1) * a1;
+      const float h1 = fm((size_t)ty.s1 * mw + tx.s0) * a0 + fm((size_t)ty.s1 * mw + tx.s1) * a1;
       rm = h0 * b0 + h1 * b1;
     }
     const float inverted = 1.0f - rm;                      // 1.0 - resized_mask_3ch        (float32)
@@ -344,7 +350,7 @@ int casync_frame_prepare(const uint8_t* regions_dev, const int32_t* geom_dev, in
 }
 
 int casync_frame_paste_back(const uint8_t* regions_dev, const int32_t* geom_dev, const int32_t* pts_dev,
-                            const float* fmasks_dev, const uint8_t* crops168_dev, const float* pred_dev, int batch,
+                            const uint8_t* crops168_dev, const float* pred_dev, int batch,
                             int max_h, int max_w, int max_width, int64_t mask_bytes, uint8_t* synth_dev,
                             uint8_t* mask_a_dev, uint8_t* mask_b_dev, int32_t* area_dev, uint8_t* out_regions_dev,
                             casync_stream stream) {
@@ -368,7 +374,7 @@ int casync_frame_paste_back(const uint8_t* regions_dev, const int32_t* geom_dev,
   hipLaunchKernelGGL(frame_dilate_kernel<false>, dim3(blocks_for(max_px), batch), dim3(256), 0, s, geom_dev, area_dev,
                      mask_b_dev, mask_a_dev);
   hipLaunchKernelGGL(frame_blend_kernel, dim3(blocks_for(max_px), batch), dim3(256), 0, s, regions_dev, geom_dev, synth_dev,
-                     mask_a_dev, fmasks_dev, out_regions_dev);
+                     mask_a_dev, out_regions_dev);
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }

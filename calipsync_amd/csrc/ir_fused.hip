@@ -221,15 +221,12 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
       // same arithmetic as upsample2x_kernel / ATen: src = dst*(in-1)/(out-1), l1 = frac, l0 = 1-l1
       const int Hl = H >> 1, Wl = W >> 1;
       const float sy = (float)(Hl - 1) / (float)(H - 1), sx = (float)(Wl - 1) / (float)(W - 1);
-      const float fy = sy * (ok ? iy : 0), fx = sx * (ok ? ix : 0);
-      const int y0 = (int)fy, x0 = (int)fx;
-      const int y1 = y0 + (y0 < Hl - 1), x1 = x0 + (x0 < Wl - 1);
-      const float ly1 = fy - y0, lx1 = fx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+      const UpsTap ty = ups_tap(sy, ok ? iy : 0, Hl), tx = ups_tap(sx, ok ? ix : 0, Wl);
       const T* lb = lo + (size_t)b * Hl * Wl * ld_lo + 4 * q;
-      const T* p00 = lb + ((size_t)y0 * Wl + x0) * ld_lo;
-      const T* p01 = lb + ((size_t)y0 * Wl + x1) * ld_lo;
-      const T* p10 = lb + ((size_t)y1 * Wl + x0) * ld_lo;
-      const T* p11 = lb + ((size_t)y1 * Wl + x1) * ld_lo;
+      const T* p00 = lb + ((size_t)ty.i0 * Wl + tx.i0) * ld_lo;
+      const T* p01 = lb + ((size_t)ty.i0 * Wl + tx.i1) * ld_lo;
+      const T* p10 = lb + ((size_t)ty.i1 * Wl + tx.i0) * ld_lo;
+      const T* p11 = lb + ((size_t)ty.i1 * Wl + tx.i1) * ld_lo;
 #pragma unroll
       for (int g = 0; g < G::KG; ++g) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -239,7 +236,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
             const f32x4 v01 = ld4(p01 + 16 * g);
             const f32x4 v10 = ld4(p10 + 16 * g);
             const f32x4 v11 = ld4(p11 + 16 * g);
-            v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+            v = ups_lerp(ty, tx, v00, v01, v10, v11);
           } else {
             v = ld4(src + 16 * g);
           }

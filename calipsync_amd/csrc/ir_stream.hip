@@ -233,15 +233,12 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
       if constexpr (UPS) {
         // same arithmetic as upsample2x_kernel / ATen: src = dst*(in-1)/(out-1), l1 = frac, l0 = 1-l1
         const int iy = ok ? iy0 + s_ry[i] : 0, ix = ok ? ix0 + s_hx[i] : 0;
-        const float fy = ups_sy * iy, fx = ups_sx * ix;
-        const int yl0 = (int)fy, xl0 = (int)fx;
-        const int yl1 = yl0 + (yl0 < Hl - 1), xl1 = xl0 + (xl0 < Wl - 1);
-        const float ly1 = fy - yl0, lx1 = fx - xl0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const UpsTap ty = ups_tap(ups_sy, iy, Hl), tx = ups_tap(ups_sx, ix, Wl);
         const float* lb = lo + (size_t)bi * Hl * Wl * ld_lo + 4 * q;
-        const float* p00 = lb + ((size_t)yl0 * Wl + xl0) * ld_lo;
-        const float* p01 = lb + ((size_t)yl0 * Wl + xl1) * ld_lo;
-        const float* p10 = lb + ((size_t)yl1 * Wl + xl0) * ld_lo;
-        const float* p11 = lb + ((size_t)yl1 * Wl + xl1) * ld_lo;
+        const float* p00 = lb + ((size_t)ty.i0 * Wl + tx.i0) * ld_lo;
+        const float* p01 = lb + ((size_t)ty.i0 * Wl + tx.i1) * ld_lo;
+        const float* p10 = lb + ((size_t)ty.i1 * Wl + tx.i0) * ld_lo;
+        const float* p11 = lb + ((size_t)ty.i1 * Wl + tx.i1) * ld_lo;
 #pragma unroll
         for (int g4 = 0; g4 < G::KG; ++g4) {
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -251,7 +248,7 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
               const f32x4 v01 = *reinterpret_cast<const f32x4*>(p01 + 16 * g4);
               const f32x4 v10 = *reinterpret_cast<const f32x4*>(p10 + 16 * g4);
               const f32x4 v11 = *reinterpret_cast<const f32x4*>(p11 + 16 * g4);
-              v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+              v = ups_lerp(ty, tx, v00, v01, v10, v11);
             } else {
               v = *reinterpret_cast<const f32x4*>(inb + (unsigned)voffA[i] + 16 * g4);
             }

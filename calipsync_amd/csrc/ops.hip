@@ -193,16 +193,13 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ i
   const int oy = (int)(t % Ho);
   const int b = (int)(t / Ho);
   const float sy = (float)(H - 1) / (float)(Ho - 1), sx = (float)(W - 1) / (float)(Wo - 1);
-  const float fy = sy * oy, fx = sx * ox;
-  const int y0 = (int)fy, x0 = (int)fx;
-  const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
-  const float ly1 = fy - y0, lx1 = fx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+  const UpsTap ty = ups_tap(sy, oy, H), tx = ups_tap(sx, ox, W);
   const T* base = in + (size_t)b * H * W * C + c;
-  const f32x4 v00 = ld4(base + ((size_t)y0 * W + x0) * C);
-  const f32x4 v01 = ld4(base + ((size_t)y0 * W + x1) * C);
-  const f32x4 v10 = ld4(base + ((size_t)y1 * W + x0) * C);
-  const f32x4 v11 = ld4(base + ((size_t)y1 * W + x1) * C);
-  const f32x4 r = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+  const f32x4 v00 = ld4(base + ((size_t)ty.i0 * W + tx.i0) * C);
+  const f32x4 v01 = ld4(base + ((size_t)ty.i0 * W + tx.i1) * C);
+  const f32x4 v10 = ld4(base + ((size_t)ty.i1 * W + tx.i0) * C);
+  const f32x4 v11 = ld4(base + ((size_t)ty.i1 * W + tx.i1) * C);
+  const f32x4 r = ups_lerp(ty, tx, v00, v01, v10, v11);
   st4(out + (((size_t)b * Ho + oy) * Wo + ox) * ldc + c, r);
 }
 

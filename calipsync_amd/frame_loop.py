@@ -73,6 +73,12 @@ import numpy as np  # noqa: E402
 GEOM_WORDS = 12
 
 
+def _split64(addr: int):
+    """A device address as two int32 words (low, high) of a geometry record."""
+    lo, hi = addr & 0xFFFFFFFF, (addr >> 32) & 0xFFFFFFFF
+    return (lo - (1 << 32) if lo >= (1 << 31) else lo), (hi - (1 << 32) if hi >= (1 << 31) else hi)
+
+
 def audio_windows_host(features: np.ndarray, indices) -> np.ndarray:
     """``FrameSynthesizer._get_audio_features`` (infer_api.py:99-145) on the host: [len(indices),32,32,32] fp32.
     Same rule as ``audio_window_gather_kernel`` (closed form of the reference's truncated zero pads: a window
@@ -173,28 +179,75 @@ class PendingBatch:
         return self._frames
 
 
-_PINNED = {}   # bytes (rounded up to 1 MiB) -> free pinned uint8 host buffers
+# Pinned staging / download buffers.  Crop boxes differ from frame to frame, so the byte count of a batch differs
+# from batch to batch: a request is served by the SMALLEST free buffer that is large enough, new buffers come in
+# power-of-two size classes (>= 1 MiB; above 64 MiB in 16 MiB steps), and the free list is capped in bytes
+# (CASYNC_PINNED_CAP_MB, default 1024): the excess is dropped, largest first, instead of growing page-locked host
+# memory (and paying a pin_memory() stall) for every new size a long clip happens to produce.
+_PINNED = []          # free pinned uint8 host buffers, any sizes
 _PINNED_LOCK = threading.Lock()
+_PINNED_CAP = int(os.environ.get("CASYNC_PINNED_CAP_MB", "1024")) << 20
+
+
+def _size_class(nbytes: int) -> int:
+    n = max(nbytes, 1 << 20)
+    if n <= (64 << 20):
+        return 1 << (n - 1).bit_length()
+    return (n + (16 << 20) - 1) // (16 << 20) * (16 << 20)
 
 
 def _acquire_pinned(nbytes: int) -> torch.Tensor:
-    size = max(1, (nbytes + (1 << 20) - 1) >> 20) << 20
     with _PINNED_LOCK:
-        free = _PINNED.setdefault(size, [])
-        if free:
-            return free.pop()
-    return torch.empty(size, dtype=torch.uint8).pin_memory()
+        best = None
+        for i, b in enumerate(_PINNED):
+            if b.numel() >= nbytes and (best is None or b.numel() < _PINNED[best].numel()):
+                best = i
+        if best is not None:
+            return _PINNED.pop(best)
+    return torch.empty(_size_class(nbytes), dtype=torch.uint8).pin_memory()
 
 
 def _release_pinned(buf: torch.Tensor) -> None:
     with _PINNED_LOCK:
-        free = _PINNED.setdefault(buf.numel(), [])
-        if len(free) < 4:
-            free.append(buf)
+        _PINNED.append(buf)
+        total = sum(b.numel() for b in _PINNED)
+        while total > _PINNED_CAP and _PINNED:
+            k = max(range(len(_PINNED)), key=lambda i: _PINNED[i].numel())
+            total -= _PINNED.pop(k).numel()
+
+
+def pinned_pool_bytes() -> int:
+    """Bytes of page-locked host memory the free list holds right now (tests, diagnostics)."""
+    with _PINNED_LOCK:
+        return sum(b.numel() for b in _PINNED)
+
+
+# Frame masks resident on the device.  The reference reads the clip's masks again for every batch and the frame
+# loop walks the same frames over and over (ping-pong order), so a caller that names its masks (`mask_keys`, e.g.
+# the frame numbers) uploads each of them once; later batches only reference the device copies.  uint8 masks
+# (= imread values, standing for value / 255) are a quarter of the float32 the reference holds on the host.
+_MASK_CACHE_CAP = int(os.environ.get("CASYNC_MASK_CACHE_MB", "4096")) << 20
+
+
+def _mask_cache(net):
+    c = getattr(net, "_mask_cache", None)
+    if c is None:
+        import collections
+        c = net._mask_cache = collections.OrderedDict()
+        net._mask_cache_bytes = 0
+    return c
+
+
+def _mask_kind(mask: np.ndarray) -> int:
+    if mask.ndim != 2:
+        raise ValueError("a frame mask must be a 2-D array")
+    if mask.dtype == np.uint8:
+        return 1
+    return 0
 
 
 def process_batch_device(net, batch_images, batch_landmarks, batch_masks, *, windows=None, features=None,
-                         frame_indices=None, copy_frames=True):
+                         frame_indices=None, copy_frames=True, mask_keys=None):
     """``FrameSynthesizer.process_batch`` with everything between the crop box and the pasted-back frame on the
     GPU: ONE upload (the crop regions of all frames, concatenated), cv2.resize -> model input -> ``net`` ->
     uint8 -> resize back -> polygon mask -> dilate -> blend, ONE download (the blended regions).
@@ -203,18 +256,24 @@ def process_batch_device(net, batch_images, batch_landmarks, batch_masks, *, win
     ``features`` [T,2,1024] on the device + ``frame_indices`` (windows gathered on the device).
     Returns the list of synthesised frames (copies; the inputs are not modified, like infer_api.py:201)."""
     return submit_batch_device(net, batch_images, batch_landmarks, batch_masks, windows=windows, features=features,
-                               frame_indices=frame_indices, copy_frames=copy_frames).result()
+                               frame_indices=frame_indices, copy_frames=copy_frames, mask_keys=mask_keys).result()
 
 
 def submit_batch_device(net, batch_images, batch_landmarks, batch_masks, *, windows=None, features=None,
-                        frame_indices=None, copy_frames=True) -> PendingBatch:
+                        frame_indices=None, copy_frames=True, mask_keys=None) -> PendingBatch:
     """The asynchronous half of ``process_batch_device``: host geometry, upload, every launch and the download
     are enqueued, the per-frame copies run on the host pool; nothing here waits for the GPU.  A caller that
     submits batch k+1 before taking ``result()`` of batch k overlaps its host work with the GPU.
 
     ``copy_frames=False`` gives up the reference's "the inputs are not modified" (infer_api.py:201): the blended
     regions are pasted into ``batch_images`` themselves, which saves a 6 MB copy per 1080p frame -- the frame copies
-    are what bounds the end-to-end rate (400 MB per 64 frames against 57 MB of regions up and down)."""
+    are what bounds the end-to-end rate (400 MB per 64 frames against 57 MB of regions up and down).
+
+    Masks: float32 in [0, 1] (the reference's ``imread(...).astype(np.float32) / 255.0``, infer_api.py:68-70) or the
+    uint8 image itself (the device divides by 255 in float32: same bits, a quarter of the bytes).  ``mask_keys``: one
+    hashable per frame (e.g. the frame number) naming its mask; a named mask is uploaded once and stays on the device
+    (``net``'s cache, CASYNC_MASK_CACHE_MB), so a clip's masks do not travel with every batch -- a whole-frame float32
+    mask is 8.3 MB per 1080p frame against 0.5-0.9 MB of crop region."""
     lib = _lib.load()
     dev = net._device()
     if dev.type != "cuda":
@@ -225,8 +284,11 @@ def submit_batch_device(net, batch_images, batch_landmarks, batch_masks, *, wind
         return PendingBatch([], [], np.zeros((0, GEOM_WORDS), dtype=np.int32), _acquire_pinned(1), done, None)
     geom = np.zeros((B, GEOM_WORDS), dtype=np.int32)
     pts = np.zeros((B, 33, 2), dtype=np.int32)
-    boxes, regions, fmasks = [], [], []
-    reg_off = synth_off = mask_off = fmask_off = 0
+    boxes, regions, fmasks = [], [], []      # fmasks: (frame, array) to upload with this batch
+    reg_off = synth_off = mask_off = fmask_bytes = 0
+    cache = _mask_cache(net) if mask_keys is not None else None
+    if mask_keys is not None and len(mask_keys) != B:
+        raise ValueError("mask_keys must name every frame of the batch")
     for i, (img, lms, mask) in enumerate(zip(batch_images, batch_landmarks, batch_masks)):
         if img is None or img.ndim != 3 or img.shape[2] != 3 or img.dtype != np.uint8:
             raise ValueError(f"frame {i}: expected a uint8 HxWx3 image")
@@ -246,10 +308,17 @@ def submit_batch_device(net, batch_images, batch_landmarks, batch_masks, *, wind
         g = geom[i]
         g[0], g[1], g[2], g[3], g[4], g[5], g[6] = reg_off, h, w, width, valid, synth_off, mask_off
         if mask is not None:
-            m = np.ascontiguousarray(mask, dtype=np.float32)
-            g[7], g[8], g[9] = fmask_off, m.shape[0], m.shape[1]
-            fmasks.append(m.reshape(-1))
-            fmask_off += m.size
+            kind = _mask_kind(mask)
+            g[7], g[8], g[9] = kind, mask.shape[0], mask.shape[1]
+            key = (mask_keys[i], kind, mask.shape) if cache is not None and mask_keys[i] is not None else None
+            hit = cache.get(key) if key is not None else None
+            if hit is not None:
+                cache.move_to_end(key)
+                g[10], g[11] = _split64(hit.data_ptr())
+            else:
+                m = np.ascontiguousarray(mask, dtype=np.uint8 if kind else np.float32)
+                fmasks.append((i, key, m, fmask_bytes))
+                fmask_bytes += (m.nbytes + 15) & ~15
         else:
             g[7] = -1
         reg_off += h * w * 3
@@ -266,10 +335,15 @@ def submit_batch_device(net, batch_images, batch_landmarks, batch_masks, *, wind
     o_geom = al(reg_off)
     o_pts = o_geom + al(geom.nbytes)
     o_fm = o_pts + al(pts.nbytes)
-    total = o_fm + 4 * fmask_off
+    total = o_fm + fmask_bytes
     stage = _acquire_pinned(total)
     st = stage.numpy()
     pool = _host_pool()
+    with torch.cuda.device(dev):
+        staged = torch.empty(total, dtype=torch.uint8, device=dev)   # allocated first: the masks' device addresses
+    for i, key, m, off in fmasks:                                    # go into the geometry records
+        g = geom[i]
+        g[10], g[11] = _split64(staged.data_ptr() + o_fm + off)
 
     def fill(dst_off, r):                       # one frame's crop region into its place in the pinned buffer
         n = r.shape[0] * r.shape[1] * 3
@@ -282,15 +356,21 @@ def submit_batch_device(net, batch_images, batch_landmarks, batch_masks, *, wind
     copies = [pool.submit(np.copy, img) for img in batch_images] if copy_frames else [_Ready(img) for img in batch_images]
     st[o_geom:o_geom + geom.nbytes] = geom.reshape(-1).view(np.uint8)
     st[o_pts:o_pts + pts.nbytes] = pts.reshape(-1).view(np.uint8)
-    if fmasks:
-        st[o_fm:total] = np.concatenate(fmasks).view(np.uint8)
+    for i, key, m, off in fmasks:
+        st[o_fm + off:o_fm + off + m.nbytes] = m.reshape(-1).view(np.uint8)
     for f in fills:
         f.result()
     with torch.cuda.device(dev):
-        staged = torch.empty(total, dtype=torch.uint8, device=dev)
         staged.copy_(stage[:total], non_blocking=True)
         base = staged.data_ptr()
-        p_regions, p_geom, p_pts, p_fm = base, base + o_geom, base + o_pts, (base + o_fm if fmasks else 0)
+        p_regions, p_geom, p_pts = base, base + o_geom, base + o_pts
+        for i, key, m, off in fmasks:     # named masks move into allocations of their own and stay (device-side copy)
+            if key is not None:
+                keep = staged[o_fm + off:o_fm + off + m.nbytes].clone()
+                cache[key] = keep
+                net._mask_cache_bytes += keep.numel()
+        while cache is not None and net._mask_cache_bytes > _MASK_CACHE_CAP and len(cache) > 1:
+            net._mask_cache_bytes -= cache.popitem(last=False)[1].numel()
         crops = torch.empty((B, 168, 168, 3), dtype=torch.uint8, device=dev)
         x = torch.empty((B, 6, 160, 160), dtype=torch.float32, device=dev)
         _lib.check(lib.casync_frame_prepare(p_regions, p_geom, B, crops.data_ptr(), x.data_ptr(),
@@ -305,7 +385,7 @@ def submit_batch_device(net, batch_images, batch_landmarks, batch_masks, *, wind
         area = torch.empty(B, dtype=torch.int32, device=dev)
         out_regions = torch.empty(reg_off, dtype=torch.uint8, device=dev)
         _lib.check(lib.casync_frame_paste_back(
-            p_regions, p_geom, p_pts, p_fm, crops.data_ptr(), pred.data_ptr(), B, max_h, max_w,
+            p_regions, p_geom, p_pts, crops.data_ptr(), pred.data_ptr(), B, max_h, max_w,
             max_width, mask_off, synth.data_ptr(), mask_a.data_ptr(), mask_b.data_ptr(), area.data_ptr(),
             out_regions.data_ptr(), stream), "casync_frame_paste_back")
         host = _acquire_pinned(reg_off)                      # the ONE download of the batch, into pinned memory

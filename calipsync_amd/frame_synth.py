@@ -86,7 +86,10 @@ class FrameSynthesizer:
         self._features_dev = None        # (id of the host array, device copy) of the clip being synthesised
 
     # ------------------------------------------------------------------ file I/O (infer_api.py:52-97)
-    def _load_single_frame(self, frame_idx: int) -> tuple:
+    def _load_single_frame(self, frame_idx: int, raw_mask: bool = False) -> tuple:
+        """(image, landmarks, mask) of a frame, as the reference returns them (mask = gray image / 255 in float32).
+        ``raw_mask`` (this loop's own calls): the mask stays the uint8 image -- the device divides by 255 in float32,
+        the same bits at a quarter of the bytes, and the host skips an 8 MB conversion per 1080p frame."""
         frame_number = str(frame_idx % self.total_frames).zfill(6)
         img = _imread(os.path.join(self.frames_dir, f"{frame_number}{self._ext}"))
         lms = np.loadtxt(os.path.join(self.positions_dir, f"{frame_number}.txt"))
@@ -95,13 +98,13 @@ class FrameSynthesizer:
             mask_path = os.path.join(self.masks_dir, f"{frame_number}{ext}")
             if os.path.exists(mask_path):
                 mask = _imread(mask_path, gray=True)
-                if mask is not None:
+                if mask is not None and not (raw_mask and mask.dtype == np.uint8):
                     mask = mask.astype(np.float32) / 255.0
                 break
         return img, lms, mask
 
-    def _load_batch_frames(self, frame_indices: list) -> tuple:
-        futures = [self.executor.submit(self._load_single_frame, i) for i in frame_indices]
+    def _load_batch_frames(self, frame_indices: list, raw_masks: bool = False) -> tuple:
+        futures = [self.executor.submit(self._load_single_frame, i, raw_masks) for i in frame_indices]
         batch_images, batch_landmarks, batch_masks = [], [], []
         for future in futures:
             img, lms, mask = future.result()
@@ -156,12 +159,13 @@ class FrameSynthesizer:
             print(f"process_batch failed, returning the original frames: {exc!r}")
             return batch_images
 
-    def _submit_batch_indices(self, batch_images, batch_landmarks, batch_masks, features_dev, indices):
+    def _submit_batch_indices(self, batch_images, batch_landmarks, batch_masks, features_dev, indices, mask_keys=None):
         """Enqueue a batch (frame_loop.submit_batch_device); a failure keeps the reference's contract of handing
         back the originals (infer_api.py:352-357) when the batch is collected."""
         try:
             return frame_loop.submit_batch_device(self.net, batch_images, batch_landmarks, batch_masks,
-                                                  features=features_dev, frame_indices=indices), batch_images
+                                                  features=features_dev, frame_indices=indices,
+                                                  mask_keys=mask_keys), batch_images
         except Exception as exc:
             print(f"process_batch failed, returning the original frames: {exc!r}")
             return None, batch_images
@@ -194,7 +198,8 @@ class FrameSynthesizer:
                     batch_end = min(batch_start + self.batch_size, total_frames)    # variable last batch
                     frame_sequence = self._generate_frame_sequence(batch_end - batch_start)
                     t0 = time.time()
-                    batch_images, batch_landmarks, batch_masks = self._load_batch_frames(frame_sequence)
+                    batch_images, batch_landmarks, batch_masks = self._load_batch_frames(
+                        frame_sequence, raw_masks=is_generate_sync_frame)
                     time_stats["load_frame"] += time.time() - t0
                     if not is_generate_sync_frame:
                         for i, original_image in enumerate(batch_images):
@@ -205,8 +210,11 @@ class FrameSynthesizer:
                     # one batch in flight: batch k+1 is loaded, cropped and enqueued while the GPU works on
                     # batch k, whose frames are yielded afterwards -- same frames, same order
                     t0 = time.time()
-                    pending, originals = self._submit_batch_indices(batch_images, batch_landmarks, batch_masks,
-                                                                    features_dev, list(range(batch_start, batch_end)))
+                    # masks are named by their file (frame number modulo the clip): each is uploaded once and stays
+                    # on the device while the walk comes back to it
+                    pending, originals = self._submit_batch_indices(
+                        batch_images, batch_landmarks, batch_masks, features_dev, list(range(batch_start, batch_end)),
+                        mask_keys=[(self.data_dir, f % self.total_frames) for f in frame_sequence])
                     in_flight.append((pending, originals, frame_sequence))
                     time_stats["process_batch"] += time.time() - t0
                     if len(in_flight) > 1:

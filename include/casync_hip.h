@@ -43,7 +43,7 @@ enum {
 /* ---- introspection (callable without a GPU) --------------------------- */
 /* Bumped on every change of a prototype, struct layout or the packed-weight layout; the ctypes
  * host (calipsync_amd/_lib.py) refuses a library whose version differs from the one it binds.   */
-#define CASYNC_ABI_VERSION 2
+#define CASYNC_ABI_VERSION 3
 int         casync_abi_version(void);
 const char* casync_last_error(void);           /* thread-local message         */
 
@@ -204,8 +204,10 @@ int casync_op_pred_to_u8(const float* pred_dev, uint8_t* out_dev, int batch, cas
  * byte buffer `regions` (h x w x 3 uint8 each, contiguous) and describes frame b in geom[b*12 .. b*12+11]
  * (int32): { region byte offset, h, w, width (xmax-xmin BEFORE the clamps: side of the synthesised square),
  * valid (1 when (width,width) == (h,w), else the frame is returned unchanged: infer_api.py:320-324), byte offset in
- * `synth`, byte offset in the two mask buffers, float offset of the optional frame mask in `fmasks` (-1 = none), its
- * height, its width, 0, 0 }.  pts: [B][33][2] int32 = the contour points already shifted / scaled / truncated
+ * `synth`, byte offset in the two mask buffers, kind of the optional frame mask (-1 = none, 0 = float32 in [0,1],
+ * 1 = uint8 standing for value / 255 -- what infer_api.py:68-70 computes on the host), its height, its width, and the
+ * low / high 32 bits of its device address (masks live in allocations of their own, so a clip's masks can stay resident
+ * on the device across batches instead of being uploaded with every batch) }.  pts: [B][33][2] int32 = the contour points already shifted / scaled / truncated
  * (infer_api.py:281-289).
  *   casync_frame_prepare: cv2.resize(region, (168,168)) -> crops168 [B,168,168,3] u8, and (x_dev != NULL) the
  *     [B,6,160,160] model input of casync_op_crop_to_input.
@@ -219,7 +221,7 @@ int casync_op_pred_to_u8(const float* pred_dev, uint8_t* out_dev, int batch, cas
 int casync_frame_prepare(const uint8_t* regions_dev, const int32_t* geom_dev, int batch, uint8_t* crops168_dev,
                          float* x_dev, casync_stream stream);
 int casync_frame_paste_back(const uint8_t* regions_dev, const int32_t* geom_dev, const int32_t* pts_dev,
-                            const float* fmasks_dev, const uint8_t* crops168_dev, const float* pred_dev, int batch,
+                            const uint8_t* crops168_dev, const float* pred_dev, int batch,
                             int max_h, int max_w, int max_width, int64_t mask_bytes, uint8_t* synth_dev,
                             uint8_t* mask_a_dev, uint8_t* mask_b_dev, int32_t* area_dev, uint8_t* out_regions_dev,
                             casync_stream stream);

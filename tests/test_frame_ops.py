@@ -231,6 +231,55 @@ def test_device_process_batch_equals_oracle(gpu_net, with_masks):
 
 
 @pytest.mark.gpu
+def test_uint8_masks_named_and_resident_equal_float_masks(gpu_net):
+    """uint8 masks (the imread image; the device divides by 255 in float32) give the pixels of the reference's float32
+    masks, and named masks are uploaded once: the second batch finds them in the model's device cache."""
+    from calipsync_amd import frame_loop
+    rng = np.random.default_rng(31)
+    imgs, lms, _ = make_frames(5, 300, 400, seed=13)
+    u8 = [rng.integers(0, 256, (300, 400) if i % 2 else (100, 150), dtype=np.uint8) for i in range(5)]
+    u8[2] = None
+    f32 = [None if m is None else m.astype(np.float32) / 255.0 for m in u8]        # infer_api.py:68-70
+    wd = torch.from_numpy(rng.standard_normal((5, 32, 32, 32)).astype(np.float32)).cuda()
+    want = frame_loop.process_batch_device(gpu_net, imgs, lms, f32, windows=wd)
+    gpu_net.__dict__.pop("_mask_cache", None)
+    keys = [("clip", i) for i in range(5)]
+    got = frame_loop.process_batch_device(gpu_net, imgs, lms, u8, windows=wd, mask_keys=keys)
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    cache = gpu_net._mask_cache
+    assert len(cache) == 4 and gpu_net._mask_cache_bytes == sum(m.size for m in u8 if m is not None)
+    ptrs = {k: v.data_ptr() for k, v in cache.items()}
+    again = frame_loop.process_batch_device(gpu_net, imgs, lms, u8, windows=wd, mask_keys=keys)
+    assert all(np.array_equal(a, b) for a, b in zip(again, want))
+    assert {k: v.data_ptr() for k, v in gpu_net._mask_cache.items()} == ptrs          # nothing was uploaded again
+
+
+def test_pinned_pool_size_classes_and_cap(monkeypatch):
+    """requests are served by the smallest free buffer that fits, new buffers come in a few size classes,
+    and the free list is capped in bytes (no pinned allocation needed to check the policy)."""
+    from calipsync_amd import frame_loop
+    assert frame_loop._size_class(1) == 1 << 20 and frame_loop._size_class((1 << 20) + 1) == 2 << 20
+    assert frame_loop._size_class(30 << 20) == 32 << 20 and frame_loop._size_class(33 << 20) == 64 << 20
+    assert frame_loop._size_class(65 << 20) == 80 << 20 and frame_loop._size_class(530 << 20) == 544 << 20
+
+    class Buf:          # stands in for a pinned tensor
+        def __init__(self, n):
+            self.n = n
+
+        def numel(self):
+            return self.n
+    monkeypatch.setattr(frame_loop, "_PINNED", [])
+    monkeypatch.setattr(frame_loop, "_PINNED_CAP", 100 << 20)
+    for n in (32, 64, 32, 16):
+        frame_loop._release_pinned(Buf(n << 20))
+    assert frame_loop.pinned_pool_bytes() == (32 + 32 + 16) << 20            # over the cap: the largest one was dropped
+    got = frame_loop._acquire_pinned(20 << 20)
+    assert got.numel() == 32 << 20                                           # smallest that fits, not the first
+    assert frame_loop._acquire_pinned(10 << 20).numel() == 16 << 20
+    assert frame_loop.pinned_pool_bytes() == 32 << 20
+
+
+@pytest.mark.gpu
 def test_frame_synthesizer_end_to_end(gpu_net, tmp_path):
     """FrameSynthesizer on a synthetic infer_data directory: device-gathered windows == host windows through
     process_batch, variable last batch, indices."""

@@ -7,7 +7,7 @@ O=$R/gpurun_out/r3_$tag
 mkdir -p $O
 cd $R
 export TMPDIR=/tmp
-timeout -k 10 400 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1 || { tail -40 $O/pytest_gpu.log; exit 1; }
+timeout -k 10 500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1 || { tail -40 $O/pytest_gpu.log; exit 1; }
 tail -3 $O/pytest_gpu.log
 for mode in 0 1; do
   CASYNC_IR_STREAM=$mode timeout -k 10 200 python tools/microbench.py ir --batch 32 > $O/ir_stream$mode.log 2>&1
