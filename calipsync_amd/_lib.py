@@ -23,6 +23,7 @@ class KernelTime(C.Structure):
 
 _PROTOS = {
     "casync_abi_version": (C.c_int, []),
+    "casync_build_flags": (C.c_int, []),
     "casync_last_error": (C.c_char_p, []),
     "casync_packed_count": (C.c_int, []),
     "casync_packed_name": (C.c_char_p, [C.c_int]),
@@ -122,6 +123,11 @@ def load() -> C.CDLL:
                            "(python -c 'import __graft_entry__ as g; g.build()')")
     _lib = lib
     return lib
+
+
+def experimental() -> bool:
+    """True when the loaded library was built with CASYNC_EXPERIMENTAL=1 (kernels measured and not adopted)."""
+    return bool(load().casync_build_flags() & 1)
 
 
 def set_option(name: str, value: int, handle=None) -> None:

@@ -203,7 +203,11 @@ struct Arena {
       {"AO", 100 * 512, 0},         {"Q", 100 * 64, 0},          {"KV", 100 * kBlocks * kKV, 0}};
   explicit Arena(const CasyncOptions& o) {
     b[E1].per_frame = b[E2].per_frame = max_unfused_expand(o);
+#ifdef CASYNC_EXPERIMENTAL
     if (!o.conv_im2col) b[IM].per_frame = 0;   // the implicit-GEMM convs need no patch buffer
+#else
+    b[IM].per_frame = 0;
+#endif
   }
   static int64_t bytes(const CasyncOptions& o, int batch, int esz = 4) {
     Arena a(o);
@@ -379,6 +383,7 @@ struct Plan {
     const long long m = (long long)B * ho * ho;
     GemmEpilogue ep;
     ep.act = 1;
+#ifdef CASYNC_EXPERIMENTAL
     if (o.conv_im2col) {
       r.run((tag + ".im2col").c_str(), kname("im2col3x3_kernel").c_str(), 0,
             dtype_size(dt()) * (double)B * ((double)hw * hw * cin + (double)ho * ho * 9 * cin),
@@ -386,6 +391,7 @@ struct Plan {
       gemm(tag, ar[Arena::IM], 9 * cin, wname, out, cout, m, cout, 9 * cin, ep);
       return;
     }
+#endif
     ep.bias = e.W(wname.substr(0, wname.size() - 1) + "b");
     ep.concurrent = concurrent ? 1 : 0;
     if (char* ctx = stream_k ? e.sk_ctx(lane, aux && r.s == aux ? 1 : 0) : nullptr) {
@@ -629,6 +635,13 @@ int check_forward_args(casync_handle h, const float* x, const float* a, float* o
 extern "C" {
 
 int casync_abi_version(void) { return CASYNC_ABI_VERSION; }
+int casync_build_flags(void) {
+#ifdef CASYNC_EXPERIMENTAL
+  return CASYNC_BUILD_EXPERIMENTAL;
+#else
+  return 0;
+#endif
+}
 int casync_packed_count(void) { return (int)layout().items.size(); }
 const char* casync_packed_name(int i) {
   return (i >= 0 && i < casync_packed_count()) ? layout().items[i].name.c_str() : nullptr;
@@ -650,8 +663,19 @@ int64_t casync_workspace_bytes_h(casync_handle h, int batch) {
 int casync_set_option(casync_handle h, const char* name, int value) {
   int* slot = nullptr;
   const int st = casync_option_ref(h ? h->opt : casync_default_options(), name, &slot);
-  if (st == CASYNC_OK) *slot = value;
-  return st;
+  if (st != CASYNC_OK) return st;
+#ifndef CASYNC_EXPERIMENTAL
+  // switches of kernels that are not in this build (measured and not adopted: gemm_experimental.inc, im2col, the
+  // deeper rings, the experimental tile shapes) can only be set to "off"
+  const bool exp_switch = !strcmp(name, "gemm_arow") || !strcmp(name, "gemm_wide") || !strcmp(name, "gemm_pipe") ||
+                          !strcmp(name, "conv_im2col");
+  if ((exp_switch && value != 0) || (!strcmp(name, "gemm_cfg") && value >= 4)) {
+    casync_set_error("option %s=%d needs a library built with CASYNC_EXPERIMENTAL=1", name, value);
+    return CASYNC_ERR_STATE;
+  }
+#endif
+  *slot = value;
+  return CASYNC_OK;
 }
 int casync_get_option(casync_handle h, const char* name, int* value) {
   CASYNC_REQUIRE(value, "get_option: null out");

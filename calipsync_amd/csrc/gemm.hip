@@ -803,452 +803,9 @@ int launch_glds_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, 
   return CASYNC_OK;
 }
 
-// =====================================================================================
-// Wide persistent ring kernel for the bf16 plan's large GEMMs (M = 256 frames x pixels per lane, K = 256..2048).
-// A bf16 k-tile is only 512 MFMA cycles per wave, an output tile of those shapes has 4-16 k-tiles, and a
-// (25600, 1024, 512) GEMM needs 12.5 us of HBM time and 10.7 us of MFMA time -- but took 55 us with 128x128
-// tiles: each tile paid its own first-load latency and its own epilogue (one workgroup per CU, nothing to hide
-// them behind), and 128x128 tiles pull 420 MB through L2 for 79 MB of operands.  This kernel
-//   * takes 256x128 tiles (315 MB through L2), eight waves of 64x64, one workgroup per CU, grid = 256;
-//   * keeps ONE LDS-DMA ring running across all the tiles of a workgroup: the loads of the next tile's first
-//     k-tiles are in flight while the current tile finishes and while its epilogue runs;
-//   * stages the epilogue through 16 KB NEXT TO the ring (32-row slabs), so the ring is never drained.
-// Loads are buffer_load ... lds with per-tile lane offsets and the k position in an SGPR (as in the two-stage
-// loop above).  Synchronisation per k-tile: counted vmcnt (tile `it` landed, `it+1` may be in flight) -> barrier
-// -> issue tile it+2 -> MFMAs.  Around an epilogue the order is: MFMAs of the tile's last k-tile -> vmcnt(0)
-// (only tile it+1 is outstanding) -> epilogue (its stores are now the oldest outstanding operations) -> issue
-// tile it+2; the iteration after it needs no wait, and the one after that waits with the usual count, which by
-// in-order retirement of loads covers the stores and tile it+2 exactly.
-// Requires M % BM == 0, N % BN == 0, K >= 4 k-tiles, operands < 2 GiB.
-// =====================================================================================
-// ds_read_b128 the compiler does not see as an LDS read (no automatic waits: the caller waits on lgkmcnt itself)
-template <int OFF>
-__device__ __forceinline__ f32x4 lds_read16_raw(unsigned lds_addr) {
-  f32x4 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
-  return v;
-}
-
-// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant expression
-template <int... S, typename F>
-__device__ __forceinline__ void for_each_int(std::integer_sequence<int, S...>, F&& f) {
-  (f(std::integral_constant<int, S>{}), ...);
-}
-// workgroup barrier that waits for this wave's LDS operations only: vector-memory operations (LDS-DMA loads of
-// the next chunk, global stores of the epilogue) stay in flight across it
-__device__ __forceinline__ void __syncthreads_lds_only() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
-template <typename T, int BM, int BN, int WM, int WN, int NST>
-__global__ __launch_bounds__(64 * WM * WN) void pw_gemm_wide_kernel(const T* __restrict__ A, int lda,
-                                                                    const T* __restrict__ W, T* __restrict__ C, int ldc,
-                                                                    int M, int N, int K, int n_ntiles, int ntiles,
-                                                                    GemmEpilogue epi, int casync_wide_skew) {
-  constexpr int NW = WM * WN, NT = 64 * NW;
-  constexpr int BK = ROWB / (int)sizeof(T);
-  constexpr int ROWS = BM + BN, STAGE = ROWS * ROWB;
-  constexpr int LPT = ROWS / (8 * NW);          // LDS-DMA instructions per wave per k-tile (8 rows each)
-  constexpr int LPA = BM / (8 * NW);            // ... of which the first LPA fetch A rows
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int SLAB = 32;                      // epilogue staging: SLAB x BN floats next to the ring
-  static_assert(ROWS % (8 * NW) == 0 && BM % (8 * NW) == 0, "whole DMA instructions per operand");
-  static_assert(NST == 3, "the wait counts below are written for three stages");
-  static_assert((size_t)NST * STAGE + (size_t)SLAB * BN * 4 <= 160 * 1024, "LDS budget");
-  static_assert(NT / (BN / V16<T>::N) == SLAB, "one epilogue pass per slab");
-  extern __shared__ __attribute__((aligned(16))) char ring[];
-  float* Cs = reinterpret_cast<float*>(ring + (size_t)NST * STAGE);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  const int wm = wave / WN, wn = wave - wm * WN;
-  const int r32 = lane & 31, kh = lane >> 5;
-  const int lrow8 = lane >> 3, lcol = lane & 7;
-  const int nk = K / BK;
-  const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int IT = my_tiles * nk;
-
-  auto tile_origin = [&](int tile, int& m0, int& n0) __attribute__((always_inline)) {   // XCD-aware bijection tile -> (m0, n0)
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = tile & 7, idx = tile >> 3;
-    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int mt = bid / n_ntiles;
-    m0 = mt * BM;
-    n0 = (bid - mt * n_ntiles) * BN;
-  };
-
-  // ---- load stream: k-tiles of this workgroup's tiles, in order, NST-1 ahead of the MFMAs ----
-  int voff[LPT];
-  int ld_k = 0, ld_ti = 0;
-  auto set_voff = [&](int tile) __attribute__((always_inline)) {
-    int m0l, n0l;
-    tile_origin(tile, m0l, n0l);
-#pragma unroll
-    for (int j = 0; j < LPT; ++j) {
-      const int r = (j * NW + wave) * 8 + lrow8;   // row inside the stage: [0,BM) = A, [BM,ROWS) = W
-      const int cs = lcol ^ ((r >> 1) & 7);        // swizzled source column
-      voff[j] = j < LPA ? (int)(((long long)(m0l + r) * lda) * (int)sizeof(T)) + cs * 16
-                        : (int)(((long long)(n0l + r - BM) * K) * (int)sizeof(T)) + cs * 16;
-    }
-  };
-  // k-skew: workgroup w starts every tile's k loop at k-tile (w / 8) % nk and wraps (a sum has no preferred order;
-  // the order is fixed per workgroup, so results repeat bit for bit).  Without it all 32 workgroups of an XCD ask for
-  // the SAME 128-B column of rows 1-2 KB apart at the same time, which lands on a few L2 channels.
-  const int skew = casync_wide_skew ? ((int)blockIdx.x >> 3) % nk : 0;
-  auto issue = [&](int stage) __attribute__((always_inline)) {   // `stage` is wave-uniform: the LDS base goes through M0
-    int kk = ld_k + skew;
-    kk = kk >= nk ? kk - nk : kk;
-    const int soff = kk * ROWB;
-#pragma unroll
-    for (int j = 0; j < LPT; ++j)
-      buffer_load_lds16(j < LPA ? static_cast<const void*>(A) : static_cast<const void*>(W),
-                        j < LPA ? epi.buf_a_bytes : epi.buf_w_bytes,
-                        (void __attribute__((address_space(3)))*)(ring + stage * STAGE + (j * NW + wave_s) * 8 * ROWB), voff[j], soff);
-    if (++ld_k == nk) {
-      ld_k = 0;
-      if (++ld_ti < my_tiles) set_voff((int)blockIdx.x + ld_ti * (int)gridDim.x);
-    }
-  };
-
-  // ---- fragment reads.  The compiler makes every LDS read it knows about wait for ALL outstanding
-  //      `buffer_load ... lds` operations (it cannot tell that they write another ring stage), which would
-  //      drain the ring before every k-tile; so the fragment reads are inline-asm ds_read_b128 with their own
-  //      lgkmcnt waits, tied to the fragment registers so the MFMAs cannot move above them.  LDS byte addresses
-  //      per lane are fixed for the kernel; the stage offset is an immediate (<= 65535: stage 2 has its own bases).
-  unsigned a_adr[2][TM][4], b_adr[2][TN][4];
-  {
-    const unsigned ring_lds = (unsigned)reinterpret_cast<uintptr_t>(ring);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int r = wm * (BM / WM) + i * 32 + r32;
-        a_adr[0][i][g] = ring_lds + r * ROWB + (((2 * g + kh) ^ ((r >> 1) & 7)) << 4);
-        a_adr[1][i][g] = a_adr[0][i][g] + 2 * STAGE;
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int r = BM + wn * (BN / WN) + j * 32 + r32;
-        b_adr[0][j][g] = ring_lds + r * ROWB + (((2 * g + kh) ^ ((r >> 1) & 7)) << 4);
-        b_adr[1][j][g] = b_adr[0][j][g] + 2 * STAGE;
-      }
-    }
-  }
-  f32x16 acc[TM][TN];
-  auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  };
-  static_assert(TM == 2 && TN == 2, "the lgkmcnt waits below are written for 2 + 2 fragments per column pair");
-  auto tile_mma = [&](auto stage_c) __attribute__((always_inline)) {
-    constexpr int S = decltype(stage_c)::value;
-    constexpr int SET = S == 2 ? 1 : 0, OFF = S == 1 ? STAGE : 0;
-    static_assert(OFF <= 65535, "ds_read offset field");
-    f32x4 fa[2][TM], fb[2][TN];
-    auto rd = [&](int g, f32x4 (&xa)[TM], f32x4 (&xb)[TN]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) xa[i] = lds_read16_raw<OFF>(a_adr[SET][i][g]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) xb[j] = lds_read16_raw<OFF>(b_adr[SET][j][g]);
-    };
-    // at most N of this wave's LDS reads still outstanding; the fragments pass through the statement
-#define CASYNC_WIDE_WAIT(N, xa, xb) \
-  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xb[0]), "+v"(xb[1]))
-    auto mma = [&](const f32x4 (&xa)[TM], const f32x4 (&xb)[TN]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = MfmaK<T>::run(xa[i], xb[j], acc[i][j]);
-    };
-    rd(0, fa[0], fb[0]);
-    rd(1, fa[1], fb[1]);
-    CASYNC_WIDE_WAIT(4, fa[0], fb[0]);
-    mma(fa[0], fb[0]);
-    rd(2, fa[0], fb[0]);
-    CASYNC_WIDE_WAIT(4, fa[1], fb[1]);
-    mma(fa[1], fb[1]);
-    rd(3, fa[1], fb[1]);
-    CASYNC_WIDE_WAIT(4, fa[0], fb[0]);
-    mma(fa[0], fb[0]);
-    CASYNC_WIDE_WAIT(0, fa[1], fb[1]);
-    mma(fa[1], fb[1]);
-#undef CASYNC_WIDE_WAIT
-  };
-
-  // ---- epilogue of the compute tile: 32-row slabs through the staging area next to the ring ----
-  int m0 = 0, n0 = 0;
-  auto epilogue = [&]() __attribute__((always_inline)) {
-    EpiCols<T> cols;                     // per-column constants: once per tile, not once per slab
-    cols.load(epi, n0 + (tid % (BN / V16<T>::N)) * V16<T>::N);
-#pragma unroll
-    for (int sl = 0; sl < BM / SLAB; ++sl) {
-      if (wm == sl / TM) {
-        const int i = sl % TM;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = 4 * kh + (r & 3) + 8 * (r >> 2);                // bit 2 of the row = kh
-            Cs[row * BN + ((wn * (BN / WN) + j * 32 + r32) ^ (kh << 5))] = acc[i][j][r];
-          }
-      }
-      __syncthreads();
-      epilogue_rows_cols<T, NT, SLAB, BN, 0, true>(Cs, m0 + sl * SLAB, n0, M, C, ldc, epi, tid, cols);
-      __syncthreads();
-    }
-  };
-
-  if (my_tiles <= 0) return;
-  // diagnostic stamps (epi.stamps, null in every product call; tools/experiments/gemm_timeline.py): the same slots
-  // as pw_gemm_glds_kernel -- entry, end of k loop / epilogue of the first two tiles, exit, tiles, shader cycles
-  auto stamp = [&](int slot) __attribute__((always_inline)) {
-    if (epi.stamps && tid == 0) epi.stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memrealtime();
-  };
-  const unsigned long long cyc0 = epi.stamps ? __builtin_amdgcn_s_memtime() : 0;
-  stamp(0);
-  set_voff((int)blockIdx.x);
-  tile_origin((int)blockIdx.x, m0, n0);
-  zero_acc();
-  issue(0);
-  if (IT > 1) issue(1);
-  int ck = 0, ct = 0, stage = 0, free_stage = 2;   // free_stage: the stage of k-tile it-1 = the one k-tile it+2 goes to
-  bool after_epilogue = false;
-  for (int it = 0; it < IT; ++it) {
-    if (!after_epilogue) {       // (an epilogue has already waited for this k-tile and ended on a barrier)
-      if (it + 1 < IT) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    }
-    after_epilogue = false;
-    const bool last_k = ck == nk - 1;
-    if (!last_k && it + 2 < IT) issue(free_stage);
-    // the MFMA part exists once per stage so that the stage offset of every ds_read is an immediate
-    if (stage == 0) tile_mma(std::integral_constant<int, 0>{});
-    else if (stage == 1) tile_mma(std::integral_constant<int, 1>{});
-    else tile_mma(std::integral_constant<int, 2>{});
-    if (last_k) {
-      wait_vmcnt<0>();           // only k-tile it+1 is outstanding; the epilogue's stores become the oldest operations
-      if (ct < 2) stamp(1 + 2 * ct);
-      epilogue();
-      if (ct < 2) stamp(2 + 2 * ct);
-      zero_acc();
-      ck = 0;
-      if (++ct < my_tiles) tile_origin((int)blockIdx.x + ct * (int)gridDim.x, m0, n0);
-      if (it + 2 < IT) issue(free_stage);
-      after_epilogue = true;
-    } else {
-      ++ck;
-    }
-    free_stage = stage;
-    stage = stage == 2 ? 0 : stage + 1;
-  }
-  stamp(5);
-  if (epi.stamps && tid == 0) {
-    epi.stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)my_tiles;
-    epi.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - cyc0;
-  }
-}
-
-template <typename T, int BM, int BN, int WM, int WN, int NST>
-int launch_wide_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, int k, const GemmEpilogue& epi,
-                  hipStream_t stream) {
-  constexpr size_t lds = (size_t)NST * (BM + BN) * ROWB + (size_t)32 * BN * sizeof(float);
-  static unsigned long long attr_once = 0;
-  auto kern = pw_gemm_wide_kernel<T, BM, BN, WM, WN, NST>;
-  if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)lds)) return st;
-  CASYNC_REQUIRE(m % BM == 0 && n % BN == 0 && k / (ROWB / (int)sizeof(T)) >= 4, "wide gemm: shape m=%d n=%d k=%d", m, n, k);
-  const int n_ntiles = n / BN;
-  const long long ntiles = (long long)(m / BM) * n_ntiles;
-  CASYNC_REQUIRE(ntiles < (1ll << 31), "gemm grid too large");
-  const unsigned long long ab = ((unsigned long long)(m - 1) * lda + k) * sizeof(T), wb = (unsigned long long)n * k * sizeof(T);
-  CASYNC_REQUIRE(ab < (1ull << 31) && wb < (1ull << 31), "gemm: operand larger than 2 GiB");
-  GemmEpilogue e2 = epi;
-  e2.buf_a_bytes = (unsigned)ab;
-  e2.buf_w_bytes = (unsigned)wb;
-  const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), lds, stream, a, lda, w, c, ldc, m, n, k, n_ntiles, (int)ntiles, e2,
-                     casync_opts().gemm_wide >= 2 ? 1 : 0);
-  CASYNC_CHECK_HIP(hipGetLastError());
-  return CASYNC_OK;
-}
-
-// =====================================================================================
-// A-stationary kernel for the bf16 plan's short-K GEMMs (K = 256 / 512, M = 256 frames x pixels per lane).
-// The ring kernels above spend their time filling LDS: every A row is read N / BN times and, shared by the eight
-// N-tiles of its M-block, arrives at first-touch latency (tools/experiments/lds_fill_rate.hip: 64 GB/s per CU for
-// that mix against 134 GB/s for an L2-resident operand).  Here a workgroup owns 128 rows of A for the whole N:
-//   * each wave keeps the MFMA A-fragments of ITS 32 rows over the whole K in registers (K / 16 x 16 B per lane,
-//     128 VGPRs at K = 512), loaded once from HBM -- A never touches LDS and is read exactly once;
-//   * W is streamed through LDS one 128-column chunk at a time, ALL its k-tiles at once (128 x K x 2 B = 128 KB at
-//     K = 512, L2-resident after the first workgroups have touched it): the loads of chunk c+1 are issued when the
-//     MFMAs of chunk c are done and land while the epilogue of chunk c runs, so the two phases alternate --
-//     MFMAs with nothing in flight / epilogue with the next chunk in flight -- and no counted wait is needed;
-//   * eight waves as 4 (rows) x 2 (64 columns each); fragment reads as raw ds_read_b128 (see pw_gemm_wide_kernel);
-//     the epilogue goes through 32 KB of staging next to the W area, 64 rows at a time.
-// Requires M % 128 == 0, N % 128 == 0, K = 16 * KSTEPS with KSTEPS in {16, 32}, operands < 2 GiB.
-// =====================================================================================
-template <typename T, int KSTEPS>
-__global__ __launch_bounds__(512) void pw_gemm_arow_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W,
-                                                           T* __restrict__ C, int ldc, int M, int N, GemmEpilogue epi) {
-  static_assert(sizeof(T) == 2, "bf16 only");
-  constexpr int K = 16 * KSTEPS, NKT = K / 64;          // k-tiles of 64 (128-B rows)
-  constexpr int BM = 128, BN = 128, NW = 8, NT = 512;
-  constexpr int TILE = BN * ROWB;                        // one k-tile of the W chunk in LDS: [128][128 B] = 16 KB
-  constexpr int LPT = BN / (8 * NW);                     // LDS-DMA instructions per wave per k-tile (= 2)
-  constexpr int HALF = 64;                               // epilogue staging: HALF x BN floats = 32 KB
-  static_assert((size_t)NKT * TILE + (size_t)HALF * BN * 4 <= 160 * 1024, "LDS budget");
-  extern __shared__ __attribute__((aligned(16))) char wlds[];
-  float* Cs = reinterpret_cast<float*>(wlds + (size_t)NKT * TILE);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r32 = lane & 31, kh = lane >> 5;
-  const int lrow8 = lane >> 3, lcol = lane & 7;
-  const int m0 = (int)blockIdx.x * BM;
-
-  // ---- A fragments: row m0 + 32 wm + r32, k = 16 s + 8 kh .. +7 for every k-step s: HBM -> registers, once ----
-  f32x4 fa[KSTEPS];
-  {
-    const T* arow = A + (size_t)(m0 + 32 * wm + r32) * lda + 8 * kh;
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) fa[s] = *reinterpret_cast<const f32x4*>(arow + 16 * s);
-  }
-
-  // ---- W chunk loads: k-tile kt of chunk n0 -> wlds + kt * TILE, rows swizzled through the source address ----
-  int voff[LPT];
-#pragma unroll
-  for (int j = 0; j < LPT; ++j) {
-    const int r = (j * NW + wave) * 8 + lrow8;           // W row inside the chunk
-    voff[j] = r * K * (int)sizeof(T) + (lcol ^ ((r >> 1) & 7)) * 16;
-  }
-  auto issue_tiles = [&](int n0, auto lo_c, auto hi_c) __attribute__((always_inline)) {   // k-tiles [lo, hi) of chunk n0
-    const int base = n0 * K * (int)sizeof(T);
-#pragma unroll
-    for (int kt = decltype(lo_c)::value; kt < decltype(hi_c)::value; ++kt)
-#pragma unroll
-      for (int j = 0; j < LPT; ++j)
-        buffer_load_lds16(W, epi.buf_w_bytes,
-                          (void __attribute__((address_space(3)))*)(wlds + kt * TILE + (j * NW + wave_s) * 8 * ROWB), voff[j],
-                          base + kt * ROWB);
-  };
-
-  // ---- B fragment addresses: row wn*64 + j*32 + r32 of the chunk, 16-B column 2g + kh of a k-tile; the k-tile
-  //      offset goes into the instruction's 16-bit offset field (k-tiles 4..7: base + 64 KB, one add per read) ----
-  const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(wlds);
-  unsigned b_adr[2][4];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int r = wn * 64 + j * 32 + r32;
-      b_adr[j][g] = lds0 + r * ROWB + (((2 * g + kh) ^ ((r >> 1) & 7)) << 4);
-    }
-
-  // diagnostic stamps (epi.stamps, null in every product call): entry, chunk 0 landed, its MFMAs done, its epilogue
-  // done, chunk 1 landed, exit; chunks; shader cycles
-  auto stamp = [&](int slot) __attribute__((always_inline)) {
-    if (epi.stamps && tid == 0) epi.stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memrealtime();
-  };
-  const unsigned long long cyc0 = epi.stamps ? __builtin_amdgcn_s_memtime() : 0;
-  stamp(0);
-  f32x16 acc[2];
-  using std::integral_constant;
-  issue_tiles(0, integral_constant<int, 0>{}, integral_constant<int, NKT>{});
-  for (int n0 = 0; n0 < N; n0 += BN) {
-    wait_vmcnt<0>();                 // this chunk of W has landed (and the previous epilogue's stores are out)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (n0 == 0) stamp(1);
-    if (n0 == BN) stamp(4);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
-    // MFMAs over the whole K; two fragment sets so that the reads of the next k-step sit under the current MFMAs
-    f32x4 fb[2][2];
-#define CASYNC_AROW_WAIT(N, x) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(x[0]), "+v"(x[1]))
-    fb[0][0] = lds_read16_raw<0>(b_adr[0][0]);
-    fb[0][1] = lds_read16_raw<0>(b_adr[1][0]);
-    for_each_int(std::make_integer_sequence<int, KSTEPS>{}, [&](auto s_c) __attribute__((always_inline)) {
-      constexpr int S = decltype(s_c)::value, CUR = S & 1, NXT = CUR ^ 1;
-      if constexpr (S == KSTEPS / 2 + 1) {
-        // every wave has issued its last read of the first half of the k-tiles (the reads of k-step KSTEPS/2
-        // were issued one step ago): after a barrier that half of the W area is free, and the first half of
-        // the next chunk is requested here, under the MFMAs of the second half, instead of in one burst of
-        // sixteen LDS-DMA instructions (60-180 issue cycles each) in front of the epilogue
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]));
-        __builtin_amdgcn_s_barrier();
-        if (n0 + BN < N) issue_tiles(n0 + BN, integral_constant<int, 0>{}, integral_constant<int, NKT / 2>{});
-      }
-      if constexpr (S + 1 < KSTEPS) {      // k-step S+1: k-tile (S+1)/4, column pair (S+1)%4
-        constexpr int KT = (S + 1) >> 2, G = (S + 1) & 3, SET = KT >> 2, OFF = (KT & 3) * TILE;
-        fb[NXT][0] = lds_read16_raw<OFF>(b_adr[0][G] + SET * 4 * TILE);
-        fb[NXT][1] = lds_read16_raw<OFF>(b_adr[1][G] + SET * 4 * TILE);
-        CASYNC_AROW_WAIT(2, fb[CUR]);
-      } else {
-        CASYNC_AROW_WAIT(0, fb[CUR]);
-      }
-      acc[0] = MfmaK<T>::run(fa[S], fb[CUR][0], acc[0]);
-      acc[1] = MfmaK<T>::run(fa[S], fb[CUR][1], acc[1]);
-    });
-#undef CASYNC_AROW_WAIT
-    __builtin_amdgcn_s_barrier();    // every wave is done reading this chunk of W
-    asm volatile("" ::: "memory");
-    if (n0 == 0) stamp(2);
-    // ---- epilogue: rows 64 h .. 64 h + 63 through the staging area.  The per-column constants are requested
-    //      BEFORE the next chunk of W: vector-memory operations retire in order, so behind the 128 KB of W they
-    //      would arrive a microsecond later ----
-    // (the thread index is made opaque per chunk: otherwise the row pointers of the epilogue are hoisted out of
-    //  the chunk loop, do not fit beside the A fragments, get spilled, and their reloads queue up behind the LDS-DMA)
-    int tid_e = tid;
-    asm volatile("" : "+v"(tid_e));
-    EpiCols<T> cols;
-    cols.load(epi, n0 + (tid_e % (BN / V16<T>::N)) * V16<T>::N);
-    if (n0 + BN < N) issue_tiles(n0 + BN, integral_constant<int, NKT / 2>{}, integral_constant<int, NKT>{});   // lands while the epilogue runs
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if ((wm >> 1) == h) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = 32 * (wm & 1) + 4 * kh + (r & 3) + 8 * (r >> 2);      // bit 2 of the row = kh
-            Cs[row * BN + ((wn * 64 + j * 32 + r32) ^ (kh << 5))] = acc[j][r];
-          }
-      }
-      __syncthreads_lds_only();
-      epilogue_rows_cols<T, NT, HALF, BN, 0, true, true>(Cs, m0 + HALF * h, n0, M, C, ldc, epi, tid_e, cols);
-      __syncthreads_lds_only();
-    }
-    if (n0 == 0) stamp(3);
-  }
-  stamp(5);
-  if (epi.stamps && tid == 0) {
-    epi.stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)(N / BN);
-    epi.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - cyc0;
-  }
-}
-
-template <typename T, int KSTEPS>
-int launch_arow_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, const GemmEpilogue& epi, hipStream_t stream) {
-  constexpr int K = 16 * KSTEPS;
-  constexpr size_t lds = (size_t)(K / 64) * 128 * ROWB + (size_t)64 * 128 * sizeof(float);
-  static unsigned long long attr_once = 0;
-  auto kern = pw_gemm_arow_kernel<T, KSTEPS>;
-  if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)lds)) return st;
-  CASYNC_REQUIRE(m % 128 == 0 && n % 128 == 0, "a-stationary gemm: shape m=%d n=%d", m, n);
-  const unsigned long long wb = (unsigned long long)n * K * sizeof(T);
-  CASYNC_REQUIRE(wb < (1ull << 31), "gemm: operand larger than 2 GiB");
-  GemmEpilogue e2 = epi;
-  e2.buf_w_bytes = (unsigned)wb;
-  hipLaunchKernelGGL(kern, dim3(m / 128), dim3(512), lds, stream, a, lda, w, c, ldc, m, n, e2);
-  CASYNC_CHECK_HIP(hipGetLastError());
-  return CASYNC_OK;
-}
+#ifdef CASYNC_EXPERIMENTAL
+#include "gemm_experimental.inc"   // pw_gemm_wide_kernel, pw_gemm_arow_kernel (measured, not adopted)
+#endif
 
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, int k,
@@ -1287,22 +844,29 @@ int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, i
   // one tile per CU anyway (then its deeper pipeline wins), else the register-staged kernel with
   // two co-resident workgroups.  The smaller tiles always take the ring.
   const long long tiles = (long long)((m + BM - 1) / BM) * (n / BN);
-  const int pipe = casync_opts().gemm_pipe;   // software-pipelined ring: number of stages (0 = the round-1 loop)
+#ifdef CASYNC_EXPERIMENTAL
+  const int pipe = casync_opts().gemm_pipe;   // software-pipelined ring: number of stages (0 = the default loops)
+#else
+  constexpr int pipe = 0;                     // deeper rings than the default 2 / 3 stages: experimental builds only
+#endif
   const size_t esz = dtype == DT_BF16 ? 2 : 4;
   const bool fits32 = ((size_t)(m - 1) * lda + k) * esz < (1ull << 31) && (size_t)n * k * esz < (1ull << 31);
   const bool ring_ok = fits32 && (pipe != 0 || (BM + BN) < 256 || tiles <= 256);
   if constexpr (WM * WN == 4 && BN >= 64) {
-    if (ring_ok && dtype == DT_BF16 && glds_mode() >= 1)
-      return pipe ? launch_glds_t<bf16_t, BM, BN, WM, WN, 3>(static_cast<const bf16_t*>(a), lda,
-                                                             static_cast<const bf16_t*>(w), static_cast<bf16_t*>(c),
-                                                             ldc, m, n, k, epi, stream, use_sk)
-                  : launch_glds_t<bf16_t, BM, BN, WM, WN, NST2>(static_cast<const bf16_t*>(a), lda,
-                                                                static_cast<const bf16_t*>(w), static_cast<bf16_t*>(c),
-                                                                ldc, m, n, k, epi, stream, use_sk);
+    if (ring_ok && dtype == DT_BF16 && glds_mode() >= 1) {
+#ifdef CASYNC_EXPERIMENTAL
+      if (pipe)
+        return launch_glds_t<bf16_t, BM, BN, WM, WN, 3>(static_cast<const bf16_t*>(a), lda, static_cast<const bf16_t*>(w),
+                                                        static_cast<bf16_t*>(c), ldc, m, n, k, epi, stream, use_sk);
+#endif
+      return launch_glds_t<bf16_t, BM, BN, WM, WN, NST2>(static_cast<const bf16_t*>(a), lda, static_cast<const bf16_t*>(w),
+                                                         static_cast<bf16_t*>(c), ldc, m, n, k, epi, stream, use_sk);
+    }
     if (ring_ok && dtype == DT_F32 && glds_mode() >= 2) {
       const float* af = static_cast<const float*>(a);
       const float* wf = static_cast<const float*>(w);
       float* cf = static_cast<float*>(c);
+#ifdef CASYNC_EXPERIMENTAL
       constexpr int STAGE_KB = (BM + BN) * ROWB / 1024;
       if constexpr (4 * STAGE_KB <= 160)
         if (pipe == 4) return launch_glds_t<float, BM, BN, WM, WN, 4>(af, lda, wf, cf, ldc, m, n, k, epi, stream, use_sk);
@@ -1310,8 +874,9 @@ int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, i
         if (pipe == 5) return launch_glds_t<float, BM, BN, WM, WN, 5>(af, lda, wf, cf, ldc, m, n, k, epi, stream, use_sk);
       if constexpr (6 * STAGE_KB <= 160)
         if (pipe == 6) return launch_glds_t<float, BM, BN, WM, WN, 6>(af, lda, wf, cf, ldc, m, n, k, epi, stream, use_sk);
-      return pipe ? launch_glds_t<float, BM, BN, WM, WN, 3>(af, lda, wf, cf, ldc, m, n, k, epi, stream, use_sk)
-                  : launch_glds_t<float, BM, BN, WM, WN, NST2>(af, lda, wf, cf, ldc, m, n, k, epi, stream, use_sk);
+      if (pipe) return launch_glds_t<float, BM, BN, WM, WN, 3>(af, lda, wf, cf, ldc, m, n, k, epi, stream, use_sk);
+#endif
+      return launch_glds_t<float, BM, BN, WM, WN, NST2>(af, lda, wf, cf, ldc, m, n, k, epi, stream, use_sk);
     }
   }
   if (dtype == DT_BF16)
@@ -1332,23 +897,39 @@ constexpr TileCfg kTiles[] = {{C128x128, 128, 128}, {C128x64, 128, 64}, {C64x64,
 
 // the A-stationary kernel (pw_gemm_arow_kernel): bf16, K = 256 / 512, whole 128-row blocks, at least half a chip of them
 bool takes_arow(int m, int n, int k, int dtype) {
+#ifndef CASYNC_EXPERIMENTAL
+  return false;
+#endif
   return dtype == DT_BF16 && m % 128 == 0 && n % 128 == 0 && (k == 512 || (k == 256 && casync_opts().gemm_arow >= 2)) &&
          m / 128 >= 128;   // K = 256 leaves two thirds of LDS unused by a lone workgroup per CU and measured equal
 }
 // the wide persistent ring kernel (pw_gemm_wide_kernel): bf16, whole 256x128 tiles, at least one per CU
 bool takes_wide(int m, int n, int k, int dtype) {
+#ifndef CASYNC_EXPERIMENTAL
+  return false;
+#endif
   return dtype == DT_BF16 && m % 256 == 0 && n % 128 == 0 && k / (ROWB / 2) >= 4 && (long long)(m / 256) * (n / 128) >= 256;
 }
 
 // does launch_cfg() send this config to the LDS-DMA ring kernel?
+inline int gemm_pipe_opt() {
+#ifdef CASYNC_EXPERIMENTAL
+  return casync_opts().gemm_pipe;
+#else
+  return 0;
+#endif
+}
 bool takes_ring(const TileCfg& t, long long tiles, int dtype) {
   return (t.id == C128x128 || t.id == C128x64 || t.id == C64x64) &&
-         (casync_opts().gemm_pipe != 0 || t.bm + t.bn < 256 || tiles <= 256) &&
+         (gemm_pipe_opt() != 0 || t.bm + t.bn < 256 || tiles <= 256) &&
          ((dtype == DT_BF16 && glds_mode() >= 1) || (dtype == DT_F32 && glds_mode() >= 2));
 }
 
 int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullptr, bool concurrent = false) {
-  const int forced = casync_opts().gemm_cfg;
+  int forced = casync_opts().gemm_cfg;
+#ifndef CASYNC_EXPERIMENTAL
+  if (forced >= C64x32) forced = -1;   // the experimental tile shapes / kernels are not in this build
+#endif
   const int nk = k / (ROWB / dtype_size(dtype));
   if (use_sk) *use_sk = false;
   if (forced == CAROW ? (takes_arow(m, n, k, dtype) || (dtype == DT_BF16 && m % 128 == 0 && n % 128 == 0 && k == 256 && m / 128 >= 128))
@@ -1419,7 +1000,7 @@ const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype, b
     snprintf(buf, sizeof(buf), "pw_gemm_wide_kernel<%s, 256, 128, 4, 2, 3>", t);
   else if (takes_ring(tc, tiles, dtype))
     snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, %d, false>", t, cfg,
-             casync_opts().gemm_pipe != 0 || tc.bm + tc.bn >= 256 ? 3 : 2);
+             gemm_pipe_opt() != 0 || tc.bm + tc.bn >= 256 ? 3 : 2);
   else
     snprintf(buf, sizeof(buf), "pw_gemm_kernel<%s, %s>", t, cfg);
   return buf;
@@ -1449,6 +1030,7 @@ int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int 
     case C128x128: return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
     case C128x64: return launch_cfg<128, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
     case C64x64: return launch_cfg<64, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
+#ifdef CASYNC_EXPERIMENTAL
     case C64x32: return launch_cfg<64, 32, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
     case C64x64W2: return launch_cfg<64, 64, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
     case CAROW:
@@ -1465,6 +1047,7 @@ int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int 
         return launch_wide_t<bf16_t, 256, 128, 4, 2, 3>(static_cast<const bf16_t*>(a), lda, static_cast<const bf16_t*>(w),
                                                         static_cast<bf16_t*>(c), ldc, m, n, k, epi, stream);
       return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
+#endif
     default: return launch_cfg<128, 32, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
   }
 }
@@ -1477,12 +1060,14 @@ int launch_conv_t(const T* in, const T* w, T* out, int ldc, int m, int n, int k,
   bool sk = false;
   const int cfg = pick_cfg(m, n, k, epi.sk_ws != nullptr, dtype, &sk, epi.concurrent != 0);
   // the ring kernel's two 48-KB-class tiles; the A "leading dimension" is unused (rows are gathered)
-  const bool pipe = casync_opts().gemm_pipe != 0;
-  if (cfg == C64x64 || n % 64 || m <= 4096)
-    return pipe ? launch_glds_t<T, 64, 64, 2, 2, 3, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C64x64)
-                : launch_glds_t<T, 64, 64, 2, 2, 2, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C64x64);
-  return pipe ? launch_glds_t<T, 128, 64, 2, 2, 3, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C128x64)
-              : launch_glds_t<T, 128, 64, 2, 2, 2, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C128x64);
+  const bool small = cfg == C64x64 || n % 64 || m <= 4096;
+#ifdef CASYNC_EXPERIMENTAL
+  if (casync_opts().gemm_pipe != 0)
+    return small ? launch_glds_t<T, 64, 64, 2, 2, 3, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C64x64)
+                 : launch_glds_t<T, 128, 64, 2, 2, 3, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C128x64);
+#endif
+  return small ? launch_glds_t<T, 64, 64, 2, 2, 2, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C64x64)
+               : launch_glds_t<T, 128, 64, 2, 2, 2, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C128x64);
 }
 }  // namespace
 
@@ -1494,7 +1079,7 @@ const char* conv3x3_gemm_kernel_name(int batch, int h, int wdt, int cin, int cou
   const int cfg = pick_cfg(m, cout, 9 * cin, stream_k, dtype, nullptr, concurrent);   // the launch's own choice
   const bool small = cfg == C64x64 || cout % 64 || m <= 4096;
   snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, 2, 2, %d, true>", dtype == DT_BF16 ? "__bf16" : "float",
-             small ? "64, 64" : "128, 64", casync_opts().gemm_pipe != 0 ? 3 : 2);
+             small ? "64, 64" : "128, 64", gemm_pipe_opt() != 0 ? 3 : 2);
   return buf;
 }
 

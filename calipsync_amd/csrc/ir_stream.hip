@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
     const float* __restrict__ lo, int ld_lo, int c_lo, const float* __restrict__ in, int ld_in,
     const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ wd,
     const float* __restrict__ bd, const float* __restrict__ w2, const float* __restrict__ b2,
-    float* __restrict__ out, int ld_out, int B, int H, int W, int res) {
+    float* __restrict__ out, int ld_out, int B, int H, int W, int res, int stagger_a, int stagger_b) {
   using G = SGeom<CIN, COUT, STRIDE>;
   constexpr int CC = G::CC, CE = G::CE, NCH = G::NCH, EROW = G::EROW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -200,6 +200,16 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
   const float ups_sy = UPS ? (float)(Hl - 1) / (float)(H - 1) : 0.f, ups_sx = UPS ? (float)(Wl - 1) / (float)(W - 1) : 0.f;
 
   issue_weights(0, 0);
+  // De-phase the workgroups.  The whole grid starts within a microsecond and every run has the same length, so
+  // without this the co-resident workgroups of a CU execute the same phase at the same time for the whole kernel:
+  // all in the MFMA-dense P1, then all in the LDS / VALU bound P2 with the matrix pipe idle (the tile kernel does not
+  // have the problem: its 6,400 short workgroups start whenever a slot frees up).  Workgroups that share a CU
+  // (blockIdx 256 apart under breadth-first dispatch) start a third of a chunk apart; a small per-workgroup skew
+  // spreads the HBM bursts of the step prologues chip-wide.  Units: 64 shader cycles.
+  {
+    int nap = stagger_a * (int)(blockIdx.x >> 8) + stagger_b * (int)(blockIdx.x & 15);
+    for (; nap > 0; nap -= 64) __builtin_amdgcn_s_sleep(64);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();   // the first chunk's weights have landed for everyone (later steps: issued and awaited one chunk ahead)
   bool first = true;
@@ -340,13 +350,15 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
           for (int ky = 0; ky < 3; ++ky) wt[ky] = *reinterpret_cast<const f32x4*>(wq + G::wWd + (ky * 3 + kx) * CC);
           const float* e0 = sE + ebk[kx];
           const float* c0 = use_carry ? e0 + cdelta : e0;
+          f32x4 e[G::NROW];      // all tap rows of the column in flight before the first multiply
+#pragma unroll
+          for (int r = 0; r < G::NROW; ++r) e[r] = *reinterpret_cast<const f32x4*>((r < G::KEEP ? c0 : e0) + r * EROW);
 #pragma unroll
           for (int r = 0; r < G::NROW; ++r) {
-            const f32x4 e = *reinterpret_cast<const f32x4*>((r < G::KEEP ? c0 : e0) + r * EROW);
 #pragma unroll
             for (int j = 0; j < G::NPX; ++j) {
               const int ky = r - j * STRIDE;
-              if (ky >= 0 && ky < 3) a[j] += e * wt[ky];
+              if (ky >= 0 && ky < 3) a[j] += e[r] * wt[ky];
             }
           }
         }
@@ -414,11 +426,12 @@ int launch_stream(const float* lo, int ld_lo, int c_lo, const float* in, int ld_
   // one run per workgroup slot of the chip; at least ir_stream_min steps per run (a run's first step has no carried
   // rows and expands all IH of them)
   const int min_steps = casync_opts().ir_stream_min > 0 ? casync_opts().ir_stream_min : 1;
-  long long grid = 256ll * G::occ;
+  const int per_cu = casync_opts().ir_stream_wgs > 0 ? casync_opts().ir_stream_wgs : G::occ;   // > occ: several rounds
+  long long grid = 256ll * per_cu;
   if (grid * min_steps > steps) grid = (steps + min_steps - 1) / min_steps;
   if (grid >= 16) grid &= ~7ll;      // whole multiples of the eight XCDs (the run -> XCD remap needs it)
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2,
-                     out, ld_out, batch, h, w, res);
+                     out, ld_out, batch, h, w, res, casync_opts().ir_stream_stagger, casync_opts().ir_stream_skew);
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }

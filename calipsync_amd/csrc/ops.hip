@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256) void dw3x3_lds_kernel(const T* __restrict__ in
   }
 }
 
+#ifdef CASYNC_EXPERIMENTAL
 // ---------------------------------------------------------------- im2col (dense 3x3)
 template <typename T>
 __global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ in,
@@ -174,6 +175,8 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ in
   if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ld4(in + (((size_t)b * H + iy) * W + ix) * C + c);
   st4(out + (size_t)t * 9 * C + (size_t)tap * C + c, v);
 }
+
+#endif   // CASYNC_EXPERIMENTAL (im2col: the implicit-GEMM convolution replaced it)
 
 // ---------------------------------------------------------------- bilinear x2
 // align_corners=True: src = dst * (in-1)/(out-1); weights as ATen computes them
@@ -500,6 +503,7 @@ int launch_dw3x3(const void* in, const float* w, const float* bias, void* out, i
   return CASYNC_OK;
 }
 
+#ifdef CASYNC_EXPERIMENTAL
 int launch_im2col3x3(const void* in, void* out, int batch, int h, int wdt, int c, int stride,
                      int pad, hipStream_t stream, int dtype) {
   CASYNC_REQUIRE(in && out && batch > 0 && c % 4 == 0, "im2col: bad args");
@@ -513,6 +517,13 @@ int launch_im2col3x3(const void* in, void* out, int batch, int h, int wdt, int c
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }
+#else
+int launch_im2col3x3(const void*, void*, int, int, int, int, int, int, hipStream_t, int) {
+  casync_set_error("im2col3x3: this library was built without CASYNC_EXPERIMENTAL (the implicit-GEMM convolution "
+                   "casync_op_conv3x3 replaced the im2col path)");
+  return CASYNC_ERR_STATE;
+}
+#endif
 
 int launch_upsample2x(const void* in, void* out, int ldc, int batch, int h, int wdt, int c,
                       hipStream_t stream, int dtype) {

@@ -35,6 +35,9 @@ const OptField kFields[] = {
     {"fuse_q", &CasyncOptions::fuse_q},
     {"ir_stream", &CasyncOptions::ir_stream},
     {"ir_stream_min", &CasyncOptions::ir_stream_min},
+    {"ir_stream_stagger", &CasyncOptions::ir_stream_stagger},
+    {"ir_stream_skew", &CasyncOptions::ir_stream_skew},
+    {"ir_stream_wgs", &CasyncOptions::ir_stream_wgs},
     {"dw_lds", &CasyncOptions::dw_lds},
     {"dw_lds_bytes", &CasyncOptions::dw_lds_bytes},
     {"conv_im2col", &CasyncOptions::conv_im2col},

@@ -45,6 +45,12 @@ enum {
  * host (calipsync_amd/_lib.py) refuses a library whose version differs from the one it binds.   */
 #define CASYNC_ABI_VERSION 3
 int         casync_abi_version(void);
+/* How the library was built.  CASYNC_BUILD_EXPERIMENTAL: it also contains the kernels that were measured and not
+ * adopted (two bf16 GEMM designs, deeper GEMM rings, extra tile shapes, the im2col convolution); their switches
+ * (casync_set_option: gemm_arow, gemm_wide, gemm_pipe, conv_im2col, gemm_cfg >= 4) and casync_op_im2col3x3 return
+ * CASYNC_ERR_STATE in a product build.                                                                          */
+#define CASYNC_BUILD_EXPERIMENTAL 1
+int         casync_build_flags(void);
 const char* casync_last_error(void);           /* thread-local message         */
 
 /* Packed-weight layout.  The host folds eval-mode BatchNorm into the conv /

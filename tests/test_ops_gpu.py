@@ -12,6 +12,19 @@ from gpu_util import dev, nchw, nhwc, ok, options, ptr, stream
 pytestmark = pytest.mark.gpu
 
 
+def needs_experimental(fn):
+    """Tests of the kernels that were measured and not adopted: they only exist in a library built with
+    CASYNC_EXPERIMENTAL=1 (VERDICT r2 #8: the product library contains what the default plan can run)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        if not _lib.experimental():
+            pytest.skip("library built without CASYNC_EXPERIMENTAL")
+        return fn(*args, **kwargs)
+    return wrapper
+
+
 def rel_err(got, ref):
     return float((got - ref).abs().max() / max(1e-6, float(ref.abs().max())))
 
@@ -146,6 +159,7 @@ def test_dw3x3(lib, b, h, w, c, stride):
 
 
 @pytest.mark.parametrize("h,c,stride,padv,cout", [(32, 128, 2, 1, 256), (16, 256, 2, 3, 512)])
+@needs_experimental
 def test_dense3x3_via_im2col(lib, h, c, stride, padv, cout):
     """conv3 (pad 1) and conv5 (pad 3: 16 -> 10) of the audio encoder."""
     g = torch.Generator().manual_seed(h)
@@ -466,6 +480,7 @@ def _bf16_big_gemm_check(lib, m, n, k, cfg, switch):
 
 @pytest.mark.parametrize("m,n,k", [(65536, 128, 256), (16384, 512, 512), (25600, 1024, 512), (16384, 640, 1024),
                                    (8192, 1024, 4096)])
+@needs_experimental
 def test_pw_gemm_bf16_wide_kernel(bf16_ops, m, n, k):
     """The 256x128 persistent ring kernel (>= 256 tiles): several tiles per workgroup, so the ring runs across
     tile boundaries and epilogues."""
@@ -475,11 +490,13 @@ def test_pw_gemm_bf16_wide_kernel(bf16_ops, m, n, k):
 
 @pytest.mark.parametrize("m,n,k", [(65536, 128, 256), (16384, 512, 512), (25600, 1024, 512), (16384, 640, 256),
                                    (32768, 2304, 512)])
+@needs_experimental
 def test_pw_gemm_bf16_a_stationary_kernel(bf16_ops, m, n, k):
     """The A-stationary kernel: A rows in registers, W streamed chunk by chunk; several chunks per workgroup."""
     _bf16_big_gemm_check(bf16_ops, m, n, k, 7, {"gemm_arow": 1})
 
 
+@needs_experimental
 def test_pw_gemm_bf16_wide_kernel_plain(bf16_ops):
     """No epilogue arithmetic: the wide kernel and the 128x128 kernel add the same products in the same k order."""
     lib = bf16_ops
@@ -567,3 +584,16 @@ def test_dw3x3_bf16(bf16_ops, b, h, w, c, stride):
     out = torch.empty(b, ref.shape[2], ref.shape[3], c, device=dev(), dtype=torch.bfloat16)
     ok(lib.casync_op_dw3x3(ptr(xd), ptr(wp), ptr(bd), ptr(out), b, h, w, c, stride, stream()))
     assert rel_err(nchw(out.float()), ref) < 2 ** -8
+
+
+def test_product_build_refuses_experimental_switches(lib):
+    """In a product build the switches of the quarantined kernels can only be 'off', and say why."""
+    if _lib.experimental():
+        pytest.skip("experimental build: the switches are live")
+    for name, value in (("gemm_arow", 1), ("gemm_wide", 1), ("gemm_pipe", 3), ("conv_im2col", 1), ("gemm_cfg", 6)):
+        with pytest.raises(RuntimeError, match="CASYNC_EXPERIMENTAL"):
+            _lib.set_option(name, value)
+        _lib.set_option(name, 0 if name != "gemm_cfg" else -1)       # 'off' is always accepted
+    z = torch.zeros(64, device=dev())
+    assert lib.casync_op_im2col3x3(ptr(z), ptr(z), 1, 4, 4, 4, 1, 1, stream()) < 0
+    assert b"CASYNC_EXPERIMENTAL" in lib.casync_last_error()
