@@ -257,11 +257,12 @@ def secondary_block(net, packed, x, a, dev, src_hash):
                       "shape": "reference self-benchmark, image_infer_v1/models/unet.py:342-347"}
     # device frame loop, median of three runs per mode
     sec["e2e"] = frame_bench.run(net, dev, batch=x.shape[0])
-    # BASELINE configs[2]: bf16 engine, B=512 (inputs = the headline's 64 frames tiled 8x; timing is data-blind)
+    # BASELINE configs[2]: bf16 engine, B=512, 512 distinct synthetic frames of the same recipe
+    from calipsync_amd import recipe
     net16 = Model(6, "hubert", precision="bf16").to(dev)
     net16.adopt_packed(packed)
-    reps = (512 + x.shape[0] - 1) // x.shape[0]
-    x16, a16 = x.repeat(reps, 1, 1, 1)[:512].contiguous(), a.repeat(reps, 1, 1, 1)[:512].contiguous()
+    x_np, a_np = recipe.make_inputs_range(0, 512)
+    x16, a16 = torch.from_numpy(x_np).to(dev), torch.from_numpy(a_np).to(dev)
     s16 = time_forward(net16, x16, a16, 2, 5, dev)
     per = {}
     for row in net16.profile(x16, a16):

@@ -793,6 +793,7 @@ extern "C" int casync_debug_ir_stamps(void* dev_words) {
   g_ir_stamps = static_cast<unsigned long long*>(dev_words);
   return CASYNC_OK;
 }
+unsigned long long* casync_ir_stamps() { return g_ir_stamps; }   // ir_stream.hip stamps the same buffer
 
 bool ir_fused_supported(int cin, int cout, int stride) {
   const int key = cin * 10000 + cout * 10 + stride;

@@ -56,14 +56,21 @@ struct SGeom {
   static constexpr int oE = 0, oD = IH * EROW, oW = oD + OP * CC, oC = oW + 2 * WBUF;
   static constexpr int CSTR = KEEP * EROW;                    // carried rows of one chunk
   static constexpr int total = oC + NCH * CSTR;
-  // LDS-DMA pieces of one weight chunk (1 KB = one wave instruction each): W1c, W2c, then [Wd | b1 | bd]
-  static constexpr int NP1 = CC * CIN / 256, NP2 = COUT * CC / 256, NP = NP1 + NP2 + 1, NPS = (NP + 3) / 4;
+  // LDS-DMA of one weight chunk, split EVENLY over the four waves (every wave issues the same number of
+  // instructions, so the counted vmcnt waits are the same immediates for all): W1c = NA1 instructions of L1 lanes
+  // per wave, W2c = one of L2 lanes, [Wd | b1 | bd] (44 x 16 B) = one of 11 lanes
+  static constexpr int W1Q = CC * CIN / 4, W2Q = COUT * CC / 4;         // floats per wave
+  static constexpr int NA1 = (W1Q + 255) / 256, L1 = W1Q >= 256 ? 64 : W1Q / 4, L2 = W2Q / 4;
+  static constexpr int NA = NA1 + 1, NBI = 1;                           // instructions per wave: group A, group B
+  static_assert(W1Q % 4 == 0 && (W1Q < 256 || W1Q % 256 == 0) && W2Q % 4 == 0 && L2 <= 64, "weight chunk pieces");
   static constexpr int occ = 160 * 1024 / (total * 4) >= 4 ? 4 : 160 * 1024 / (total * 4);
   static_assert(NEW * BT % 4 == 0 && NEW * TAIL <= 16 && KEEP * BT <= 2 && KEEP * TAIL <= 16, "tile slots");
-  static_assert(NCH % 2 == 0 && (CC * CIN) % 256 == 0 && (COUT * CC) % 256 == 0, "weight chunk pieces");
+  static_assert(NCH % 2 == 0 && NCH >= 4, "two weight buffers, parts issued up to two chunks ahead");
   static_assert(total * 4 <= 160 * 1024 && occ >= 1, "LDS budget");
   static_assert(oD % 4 == 0 && oW % 4 == 0 && oC % 4 == 0 && CSTR % 4 == 0 && WBUF % 4 == 0, "16-B aligned carve");
 };
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // 16 B per lane from a buffer straight into LDS (wave-uniform LDS base + lane * 16); see gemm.hip
 __device__ __forceinline__ void dma16(const void* base, unsigned bytes, float* lds, int voff, int soff) {
@@ -78,8 +85,20 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
     const float* __restrict__ lo, int ld_lo, int c_lo, const float* __restrict__ in, int ld_in,
     const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ wd,
     const float* __restrict__ bd, const float* __restrict__ w2, const float* __restrict__ b2,
-    float* __restrict__ out, int ld_out, int B, int H, int W, int res, int stagger_a, int stagger_b) {
+    float* __restrict__ out, int ld_out, int B, int H, int W, int res, int stagger_a, int stagger_b,
+    unsigned long long* __restrict__ stamps) {
   using G = SGeom<CIN, COUT, STRIDE>;
+  // diagnostic only (null in every product call; tools/experiments/ir_timeline.py): shader cycles wave 0 of a
+  // workgroup spends in the step prologues / P1 / P2 / P3 (each including the wait or barrier that ends it) / the
+  // step epilogues, summed over its run; word 5 = steps of the run
+  unsigned long long t_mark = stamps ? __builtin_amdgcn_s_memtime() : 0, t_phase[5] = {0, 0, 0, 0, 0};
+  auto mark = [&](int slot) {
+    if (stamps) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      t_phase[slot] += t - t_mark;
+      t_mark = t;
+    }
+  };
   constexpr int CC = G::CC, CE = G::CE, NCH = G::NCH, EROW = G::EROW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sE = smem + G::oE;
@@ -156,42 +175,49 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
     voffO[i] = (py * Wo + l15) * ld_out + 4 * q;
     voffX[i] = ((py + 1) * W + l15 + 1) * ld_in + 4 * q;    // residual (stride 1): the block input at the output pixel
   }
-  // weight pieces of this wave: piece p = 4 * s + wave
-  int voffW[G::NPS];
+  // ---- weights by LDS-DMA.  Two buffers per part; every part of chunk c is requested one to two chunks before
+  //      its first reader, as soon as the LAST reader of the chunk it overwrites is behind a barrier:
+  //        group A(c), behind barrier 1 of chunk c:  W1[c+2] -> buffer c&1 (P1(c) was its last reader),
+  //                                                   W2[c+1] -> buffer (c+1)&1 (P3(c-1) was)
+  //        group B(c), behind barrier 2 of chunk c:  [Wd|b1|bd][c+2] -> buffer c&1 (P2(c) was)
+  //      and awaited with COUNTED waits (loads retire in order): in front of barrier 2 of chunk c everything up to
+  //      A(c-1) has landed (W2[c] for P3(c), W1[c+1] for P1(c+1)), in front of barrier 1 of chunk c everything up to
+  //      B(c-2) (Wd[c] for P2(c)) -- both leave the NA + NBI youngest requests in flight.  A request has a whole chunk
+  //      (~4 us) to arrive; round-3's first version gave it the length of P2 and stalled on every chunk.
+  //      Other vector-memory operations (step prologue loads, residual loads, output stores) only make these waits
+  //      stricter.  c runs over the chunks of ALL steps of the run; weights repeat with period NCH.
+  int voffW1[G::NA1];
 #pragma unroll
-  for (int s = 0; s < G::NPS; ++s) {
-    const int p = 4 * s + wave;
-    if (p < G::NP1) {                 // rows of W1c: LDS float offset f -> (row, 16-B slot); source column = slot ^ key
-      const int f = p * 256 + lane * 4, row = f / CIN, slot = (f - row * CIN) >> 2;
-      const int src_col4 = (xs<CIN>(row, 4 * slot) - row * CIN) >> 2;    // xs is an involution on the slot index
-      voffW[s] = (row * CIN + 4 * src_col4) * 4;
-    } else if (p < G::NP1 + G::NP2) {
-      const int f = (p - G::NP1) * 256 + lane * 4, row = f / CC, slot = (f - row * CC) >> 2;
-      const int src_col4 = (xs<CC>(row, 4 * slot) - row * CC) >> 2;
-      voffW[s] = (row * CE + 4 * src_col4) * 4;
-    } else {
-      voffW[s] = 0;
-    }
+  for (int j = 0; j < G::NA1; ++j) {   // LDS float offset f inside W1c -> (row, 16-B slot); source column = slot ^ key
+    const int f = wave * G::W1Q + j * 256 + lane * 4, row = f / CIN, slot = (f - row * CIN) >> 2;
+    const int src_col4 = (xs<CIN>(row, 4 * slot) - row * CIN) >> 2;      // xs is an involution on the slot index
+    voffW1[j] = (row * CIN + 4 * src_col4) * 4;
   }
-  // [Wd | b1 | bd] piece: 11 rows of 16 floats, lane -> (row t, quad)
-  const int wd_t = lane >> 2;
-  const float* wd_src = (wd_t < 9 ? wd + (size_t)wd_t * CE : (wd_t == 9 ? b1 : bd)) + (lane & 3) * 4;
-  auto issue_weights = [&](int ch, int buf) {   // chunk ch -> weight buffer buf (all four waves, 1-2 pieces each)
-    float* wb = sW + buf * G::WBUF;
+  int voffW2;
+  {
+    const int f = wave * G::W2Q + lane * 4, row = f / CC, slot = (f - row * CC) >> 2;
+    const int src_col4 = (xs<CC>(row, 4 * slot) - row * CC) >> 2;
+    voffW2 = (row * CE + 4 * src_col4) * 4;
+  }
+  // [Wd | b1 | bd]: 11 rows of 16 floats = 44 lanes, 11 per wave: lane -> (row t, quad)
+  const int wd_i = wave * 11 + (lane < 11 ? lane : 0), wd_t = wd_i >> 2;
+  const float* wd_src = (wd_t < 9 ? wd + (size_t)wd_t * CE : (wd_t == 9 ? b1 : bd)) + (wd_i & 3) * 4;
+  auto issue_a = [&](int c) {
+    const int c2 = (c + 2) % NCH, c1 = (c + 1) % NCH;
+    float* w1b = sW + (c & 1) * G::WBUF + G::wW1 + wave * G::W1Q;
+    float* w2b = sW + ((c + 1) & 1) * G::WBUF + G::wW2 + wave * G::W2Q;
 #pragma unroll
-    for (int s = 0; s < G::NPS; ++s) {
-      const int p = 4 * s + wave;
-      if (p < G::NP1) {
-        dma16(w1, (unsigned)CE * CIN * 4, wb + G::wW1 + p * 256, voffW[s], ch * CC * CIN * 4);
-      } else if (p < G::NP1 + G::NP2) {
-        dma16(w2, (unsigned)COUT * CE * 4, wb + G::wW2 + (p - G::NP1) * 256, voffW[s], ch * CC * 4);
-      } else if (p == G::NP1 + G::NP2) {
-        if (lane < 44)
-          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(wd_src + ch * CC),
-                                           (void __attribute__((address_space(3)))*)(wb + G::wWd), 16, 0, 0);
-      }
-    }
+    for (int j = 0; j < G::NA1; ++j)
+      if (G::L1 == 64 || lane < G::L1) dma16(w1, (unsigned)CE * CIN * 4, w1b + j * 256, voffW1[j], c2 * CC * CIN * 4);
+    if (G::L2 == 64 || lane < G::L2) dma16(w2, (unsigned)COUT * CE * 4, w2b, voffW2, c1 * CC * 4);
   };
+  auto issue_b = [&](int c) {
+    const int c2 = (c + 2) % NCH;
+    if (lane < 11)
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(wd_src + c2 * CC),
+                                       (void __attribute__((address_space(3)))*)(sW + (c & 1) * G::WBUF + G::wWd + wave * 44), 16, 0, 0);
+  };
+  constexpr int FLIGHT = G::NA + G::NBI;       // requests of this wave that may stay in flight across a counted wait
 
   // carried rows: wave 0 copies E rows NEW .. IH-1 of a chunk into the chunk's carry slot (this lane's pieces)
   constexpr int CPL = (G::CSTR / 4 + 63) / 64;
@@ -199,7 +225,11 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
   const int Hl = H >> 1, Wl = W >> 1;
   const float ups_sy = UPS ? (float)(Hl - 1) / (float)(H - 1) : 0.f, ups_sx = UPS ? (float)(Wl - 1) / (float)(W - 1) : 0.f;
 
-  issue_weights(0, 0);
+  // prime: chunks 0 and 1 completely except W2[1] (A(-2), B(-2), A(-1), B(-1) of the scheme above)
+  issue_a(-2 + NCH);   // W1[0] -> buffer 0, W2[NCH-1] -> buffer 1 (overwritten by A(0) before anyone reads it)
+  issue_b(-2 + NCH);   // Wd[0] -> buffer 0
+  issue_a(-1 + NCH);   // W1[1] -> buffer 1, W2[0] -> buffer 0
+  issue_b(-1 + NCH);   // Wd[1] -> buffer 1
   // De-phase the workgroups.  The whole grid starts within a microsecond and every run has the same length, so
   // without this the co-resident workgroups of a CU execute the same phase at the same time for the whole kernel:
   // all in the MFMA-dense P1, then all in the LDS / VALU bound P2 with the matrix pipe idle (the tile kernel does not
@@ -218,7 +248,6 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
   for (long long u = u0; u < u1; ++u) {
     const bool fresh = first || sy == 0;
     first = false;
-    const bool more = u + 1 < u1;
     const int y0 = sy * G::TH, x0 = sx * TW;                   // output origin of the step
     const int iy0 = y0 * STRIDE - 1, ix0 = x0 * STRIDE - 1;    // input pixel of halo (0, 0)
     const bool border = iy0 < 0 || ix0 < 0 || iy0 + G::IH > H || ix0 + G::IW > W;
@@ -287,6 +316,10 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
 #pragma unroll
       for (int n = 0; n < G::NT3; ++n) acc3[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 xres[G::MT3][G::NT3];
+    if (stamps) {
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(fa[0][0]) : "memory");   // the prologue ends when the fragments are in
+      mark(0);
+    }
 
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
@@ -322,10 +355,10 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
         if (has_x) p1(std::integral_constant<int, G::MT1>{});
         else p1(std::integral_constant<int, G::NB>{});
       }
-      __syncthreads();  // E complete; every wave is done with the previous chunk's P3 (and its weight buffer)
-      // the next chunk's weights (the next step's first chunk behind the last one) into the other buffer
-      if (ch + 1 < NCH) issue_weights(ch + 1, (ch + 1) & 1);
-      else if (more) issue_weights(0, 0);
+      wait_vm<FLIGHT>();   // this wave's share of [Wd|b1|bd] of THIS chunk (group B, two chunks ago) has landed
+      __syncthreads();     // E complete; every wave is done with the previous chunk's P3; Wd visible
+      mark(1);
+      issue_a(ch);
       if (res && ch == NCH - 1) {      // residual input in the accumulator layout, in flight under P2 / P3
 #pragma unroll
         for (int i = 0; i < G::MT3; ++i)
@@ -374,8 +407,10 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
           }
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the next weights has landed
-      __syncthreads();  // D complete, the next weights visible
+      wait_vm<FLIGHT>();   // this wave's share of group A of the previous chunk: W2 of this chunk, W1 of the next
+      __syncthreads();     // D complete, those weights visible
+      mark(2);
+      issue_b(ch);
 
       // ---- P3: project GEMM, acc3[pixel][cout] += D[pixel][CC] x W2c^T (W2c = A operand, pixels = B operand) ----
       {
@@ -392,6 +427,8 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
             for (int n = 0; n < G::NT3; ++n) acc3[i][n] = mfma16(fw[n][s], fd[i][s], acc3[i][n]);
       }
       // no barrier here: the next P1 writes E only, which nobody reads until after its barrier
+      if (stamps) asm volatile("s_nop 0" ::"v"(acc3[0][0]));   // keep P3's MFMAs in front of the stamp
+      mark(3);
     }
 
     // ---- epilogue: + b2, LReLU (+ x), straight from the accumulator layout: 64-B row pieces per pixel ----
@@ -406,11 +443,20 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
       }
     }
 
+    if (stamps) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      mark(4);
+    }
     if (++sy == NSY) {
       sy = 0;
       if (++sx == NSX) sx = 0, ++bi;
     }
   }
+  if (stamps && tid == 0 && blockIdx.x < 4096) {
+    for (int k = 0; k < 5; ++k) stamps[(size_t)blockIdx.x * 8 + k] = t_phase[k];
+    stamps[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)(u1 - u0);
+  }
+  wait_vm<0>();   // the weight requests issued ahead of the (non-existent) next chunks still target this workgroup's LDS
 }
 
 template <int CIN, int COUT, int STRIDE, bool UPS>
@@ -431,7 +477,8 @@ int launch_stream(const float* lo, int ld_lo, int c_lo, const float* in, int ld_
   if (grid * min_steps > steps) grid = (steps + min_steps - 1) / min_steps;
   if (grid >= 16) grid &= ~7ll;      // whole multiples of the eight XCDs (the run -> XCD remap needs it)
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2,
-                     out, ld_out, batch, h, w, res, casync_opts().ir_stream_stagger, casync_opts().ir_stream_skew);
+                     out, ld_out, batch, h, w, res, casync_opts().ir_stream_stagger, casync_opts().ir_stream_skew,
+                     casync_ir_stamps());
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }

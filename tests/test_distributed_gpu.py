@@ -66,3 +66,58 @@ def test_bench_launches_its_own_ranks():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["world_size"] == 2 and r["config"]["global_batch"] == 32
     assert r["value"] > 0 and r["config"]["strong_scaling"]["global_batch"] == 64
+
+
+_SHARD_WORKER = r"""
+import os, sys
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from calipsync_amd import recipe
+from calipsync_amd.sharding import broadcast_packed_weights, shard_range
+from calipsync_amd.unet import Model
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("gloo", rank=rank, world_size=world)      # two ranks share the one GPU: RCCL refuses that
+src = None
+if rank == 0:
+    src = Model(6, "hubert").to(dev)
+    src.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe.make_state_dict().items()})
+packed = broadcast_packed_weights(src, dev)
+net = Model(6, "hubert").to(dev)
+net.adopt_packed(packed)
+net.set_option("gemm_streamk", 0)                                  # batch-invariant bits
+start, count = shard_range(6, rank, world)
+x, a = recipe.make_inputs_range(start, count)
+out = net(torch.from_numpy(x).to(dev), torch.from_numpy(a).to(dev))
+torch.save({"start": start, "count": count, "out": out.cpu()}, sys.argv[2] + f".{rank}")
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_world2_shards_equal_the_single_process_forward(recipe_sd, tmp_path):
+    """Two ranks (sharing the GPU, weights broadcast over gloo) each run their contiguous shard of 6 frames
+    (shard_range(6, r, 2)); the concatenated shard outputs equal the single-process forward bit for bit."""
+    worker = tmp_path / "worker.py"
+    worker.write_text(_SHARD_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(worker), REPO, str(tmp_path / "out")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+    parts = sorted((torch.load(str(tmp_path / f"out.{r}")) for r in range(2)), key=lambda d: d["start"])
+    assert [(d["start"], d["count"]) for d in parts] == [(0, 3), (3, 3)]
+    dev = torch.device("cuda", 0)
+    net = Model(6, "hubert").to(dev)
+    net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe_sd.items()})
+    net.set_option("gemm_streamk", 0)
+    x, a = recipe.make_inputs_range(0, 6)
+    ref = net(torch.from_numpy(x).to(dev), torch.from_numpy(a).to(dev)).cpu()
+    assert torch.equal(torch.cat([d["out"] for d in parts]), ref)

@@ -43,8 +43,11 @@ for name, cin, cout, stride, hw in SHAPES:
     run()
     torch.cuda.synchronize()
     lib.casync_debug_ir_stamps(0)
-    st = stamps.cpu().numpy().reshape(-1, 8)[:, :5]
-    st = st[st.sum(1) > 0]
+    raw = stamps.cpu().numpy().reshape(-1, 8)
+    raw = raw[raw[:, :5].sum(1) > 0]
+    st = raw[:, :5].astype(np.float64)
+    if (raw[:, 5] > 0).all():        # the streaming kernel sums over the steps of a run (word 5): per step
+        st = st / raw[:, 5:6]
     med = np.median(st, axis=0)
     tot = med.sum()
     nch = ce // 16
