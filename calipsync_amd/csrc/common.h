@@ -211,7 +211,7 @@ bool ir_fused_supported(int cin, int cout, int stride);
 const char* ir_fused_kernel_name(int cin, int cout, int stride, int dtype = DT_F32, bool ups = false, int h = 0, int w = 0);
 // row-streaming variant (ir_stream.hip): fp32, stride 1, whole 8 x 16 steps
 unsigned long long* casync_ir_stamps();   // diagnostic stamp buffer of this thread (casync_debug_ir_stamps), or null
-bool ir_stream_supported(int cin, int cout, int stride, int h, int w, bool ups);
+bool ir_stream_supported(int cin, int cout, int stride, int h, int w, bool ups, int res);
 const char* ir_stream_kernel_name(int cin, int cout, int stride, bool ups);
 int launch_ir_stream(const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const void* w1, const float* b1,
                      const float* wd, const float* bd, const void* w2, const float* b2, void* out, int ld_out,

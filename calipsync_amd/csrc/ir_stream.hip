@@ -26,6 +26,15 @@
 // Shapes: fp32, stride 1 (8 x 16 output pixels per step) or stride 2 (4 x 16), H a multiple of 8, W of 16 * stride.
 // Everything else (ragged shapes, bf16) stays with ir_fused.hip.
 //
+// Balance.  The waves of a workgroup meet at two barriers per chunk, so what counts is the busiest wave of each
+// barrier interval, not the sum.  (1) The interval [barrier 2 of chunk c, barrier 1 of chunk c+1] holds P3(c) and
+// P1(c+1).  Wave 3 expands one tile more than the others (the row tails), so it takes correspondingly fewer of the
+// project GEMM's (pixel tile, channel tile) units: P3Map below splits the units so that P1 + P3 MFMAs are equal.
+// (2) The rows a step hands to the next one are never copied: P1 writes them straight into a carry slot and this
+// step's own P2 reads them from there.  Slots rotate: chunk c of a step reads slot (c - rot) and writes slot
+// (c - 1 - rot) mod (NCH + 1) -- the slot chunk c-1 consumed a whole chunk earlier -- and the next step (rot + 1)
+// finds its rows where this one put them.  One slot more than chunks, no double buffer.
+//
 // P1 tile slots of a wave (16 pixels each, a tile never straddles a halo row, see ir_fused.hip e_off()):
 //   slots 0 .. NB-1   body tiles of the NEW rows (rows KEEP .. IH-1), always
 //   slot NB           wave 3: the row tails (hx >= 16 * BT) of the new rows, always
@@ -53,9 +62,19 @@ struct SGeom {
   static constexpr int NPX = OP / 64, NROW = (NPX - 1) * STRIDE + 3;   // P2: pixels stacked in y per thread, tap rows
   // one weight buffer: W1c [CC][CIN], W2c [COUT][CC], Wd [9][CC], b1 [CC], bd [CC]
   static constexpr int wW1 = 0, wW2 = CC * CIN, wWd = wW2 + COUT * CC, wB = wWd + 9 * CC, WBUF = wB + 2 * CC;
-  static constexpr int oE = 0, oD = IH * EROW, oW = oD + OP * CC, oC = oW + 2 * WBUF;
+  // E holds rows 0 .. NEW-1 of the expanded tile only: rows NEW .. IH-1 live in a carry slot from the start
+  static constexpr int oE = 0, oD = NEW * EROW, oW = oD + OP * CC, oC = oW + 2 * WBUF;
   static constexpr int CSTR = KEEP * EROW;                    // carried rows of one chunk
-  static constexpr int total = oC + NCH * CSTR;
+  static constexpr int NSLOT = NCH + 1;
+  static constexpr int total = oC + NSLOT * CSTR;
+  // project GEMM units (pixel tile t, channel tile n), u = t * NT3 + n, split over the waves: wave 3 carries one
+  // P1 tile (4 * KG MFMAs = KG units' worth) more than the others in a carry step
+  static constexpr int NTP = OP / 16, U3 = NTP * NT3;
+  static constexpr int cnt3 = U3 >= 3 * KG ? (U3 - 3 * KG) / 4 : 0;
+  static constexpr int rest = U3 - cnt3;
+  static constexpr int ucount(int w) { return w == 3 ? cnt3 : rest / 3 + (w < rest % 3 ? 1 : 0); }
+  static constexpr int ustart(int w) { return w == 0 ? 0 : ustart(w - 1) + ucount(w - 1); }
+  static constexpr int MAXU = rest / 3 + (rest % 3 ? 1 : 0) > cnt3 ? rest / 3 + (rest % 3 ? 1 : 0) : cnt3;
   // LDS-DMA of one weight chunk, split EVENLY over the four waves (every wave issues the same number of
   // instructions, so the counted vmcnt waits are the same immediates for all): W1c = NA1 instructions of L1 lanes
   // per wave, W2c = one of L2 lanes, [Wd | b1 | bd] (44 x 16 B) = one of 11 lanes
@@ -63,7 +82,8 @@ struct SGeom {
   static constexpr int NA1 = (W1Q + 255) / 256, L1 = W1Q >= 256 ? 64 : W1Q / 4, L2 = W2Q / 4;
   static constexpr int NA = NA1 + 1, NBI = 1;                           // instructions per wave: group A, group B
   static_assert(W1Q % 4 == 0 && (W1Q < 256 || W1Q % 256 == 0) && W2Q % 4 == 0 && L2 <= 64, "weight chunk pieces");
-  static constexpr int occ = 160 * 1024 / (total * 4) >= 4 ? 4 : 160 * 1024 / (total * 4);
+  // workgroups per CU: what LDS allows, at most 3 (a fourth wave per SIMD would need <= 128 registers: spills)
+  static constexpr int occ = 160 * 1024 / (total * 4) >= 3 ? 3 : 160 * 1024 / (total * 4);
   static_assert(NEW * BT % 4 == 0 && NEW * TAIL <= 16 && KEEP * BT <= 2 && KEEP * TAIL <= 16, "tile slots");
   static_assert(NCH % 2 == 0 && NCH >= 4, "two weight buffers, parts issued up to two chunks ahead");
   static_assert(total * 4 <= 160 * 1024 && occ >= 1, "LDS budget");
@@ -88,11 +108,13 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
     float* __restrict__ out, int ld_out, int B, int H, int W, int res, int stagger_a, int stagger_b,
     unsigned long long* __restrict__ stamps) {
   using G = SGeom<CIN, COUT, STRIDE>;
+  constexpr bool RES = CIN == COUT && STRIDE == 1;   // the blocks with a residual connection (module/unet.py:14); the
+  (void)res;                                         // launcher sends res != RES to the tile kernel
   // diagnostic only (null in every product call; tools/experiments/ir_timeline.py): shader cycles wave 0 of a
   // workgroup spends in the step prologues / P1 / P2 / P3 (each including the wait or barrier that ends it) / the
   // step epilogues, summed over its run; word 5 = steps of the run
   unsigned long long t_mark = stamps ? __builtin_amdgcn_s_memtime() : 0, t_phase[5] = {0, 0, 0, 0, 0};
-  auto mark = [&](int slot) {
+  auto mark = [&](int slot) __attribute__((always_inline)) {
     if (stamps) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
       t_phase[slot] += t - t_mark;
@@ -148,11 +170,16 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
     s_hx[G::NB] = 16 * (wave % G::BT) + l15;
   }
   if (!x_live) s_ry[G::NB] = 0, s_hx[G::NB] = 0;
-  int voffA[G::MT1], ewr[G::MT1];      // float offsets: input pixel relative to the step's halo origin, E slot
+  // float offsets: input pixel relative to the step's halo origin; where the expanded pixel goes -- relative to E for
+  // rows < NEW, relative to the chunk's NEW carry slot for the rows the next step inherits (ecar)
+  int voffA[G::MT1], ewr[G::MT1];
+  int ecar = 0;                        // bit i: slot i of this lane goes to the carry slot
 #pragma unroll
   for (int i = 0; i < G::MT1; ++i) {
     voffA[i] = (s_ry[i] * W + s_hx[i]) * ld_in + 4 * q;
-    ewr[i] = e_off<STRIDE, CC, G::IW>(s_ry[i], s_hx[i], q);
+    const bool car = s_ry[i] >= G::NEW;
+    ecar |= car ? 1 << i : 0;
+    ewr[i] = e_off<STRIDE, CC, G::IW>(car ? s_ry[i] - G::NEW : s_ry[i], s_hx[i], q) + (car ? 0 : G::oE);
   }
   // W1 fragment offsets (the MFMA A operand: row = channel l15 of the chunk, 16-B column 4g + q, swizzled)
   int w1fr[G::KG];
@@ -160,21 +187,15 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
   for (int g4 = 0; g4 < G::KG; ++g4) w1fr[g4] = G::wW1 + xs<CIN>(l15, 16 * g4 + 4 * q);
   const int w2fr = G::wW2 + xs<CC>(l15, 4 * q);          // + 16 * n rows = + 256 * n floats (key is n-independent)
   // P2: thread = channel quad x NPX pixels stacked in y
-  const int p2_c4 = (tid & 3) * 4, p2_px = (tid >> 2) & 15, p2_py0 = wave * G::NPX;
-  int ebk[3], dwr[G::NPX];
+  const int p2_c4 = (tid & 3) * 4, p2_px = (tid >> 2) & 15, p2_py0 = wave * G::NPX, p2_row0 = p2_py0 * STRIDE;
+  int ebk[3];                           // tap-column offsets in this wave's first tap row of E
 #pragma unroll
-  for (int kx = 0; kx < 3; ++kx) ebk[kx] = e_off<STRIDE, CC, G::IW>(p2_py0 * STRIDE, p2_px * STRIDE + kx, p2_c4 >> 2);
-#pragma unroll
-  for (int j = 0; j < G::NPX; ++j) dwr[j] = xs<CC>((p2_py0 + j) * TW + p2_px, p2_c4);
-  // P3 / epilogue: tile t = wave * MT3 + i is output row t of the step, lane pixel l15, channels 16n + 4q ..
-  int dfr[G::MT3], voffO[G::MT3], voffX[G::MT3];
-#pragma unroll
-  for (int i = 0; i < G::MT3; ++i) {
-    const int py = wave * G::MT3 + i;
-    dfr[i] = xs<CC>(16 * py + l15, 4 * q);
-    voffO[i] = (py * Wo + l15) * ld_out + 4 * q;
-    voffX[i] = ((py + 1) * W + l15 + 1) * ld_in + 4 * q;    // residual (stride 1): the block input at the output pixel
-  }
+  for (int kx = 0; kx < 3; ++kx) ebk[kx] = e_off<STRIDE, CC, G::IW>(p2_row0, p2_px * STRIDE + kx, p2_c4 >> 2);
+  const int dwr0 = xs<CC>(p2_py0 * TW + p2_px, p2_c4);   // + 16 rows = + 256 floats per further pixel (same key)
+  // P3 / epilogue: unit (t, n) = pixel tile t (output row t of the step: lane pixel l15), channels 16n + 4q .. +3
+  const int dfr0 = xs<CC>(l15, 4 * q);                     // + 256 * t floats (the key does not depend on t)
+  const int laneO = l15 * ld_out + 4 * q;                  // + t * Wo * ld_out + 16 * n
+
   // ---- weights by LDS-DMA.  Two buffers per part; every part of chunk c is requested one to two chunks before
   //      its first reader, as soon as the LAST reader of the chunk it overwrites is behind a barrier:
   //        group A(c), behind barrier 1 of chunk c:  W1[c+2] -> buffer c&1 (P1(c) was its last reader),
@@ -202,7 +223,7 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
   // [Wd | b1 | bd]: 11 rows of 16 floats = 44 lanes, 11 per wave: lane -> (row t, quad)
   const int wd_i = wave * 11 + (lane < 11 ? lane : 0), wd_t = wd_i >> 2;
   const float* wd_src = (wd_t < 9 ? wd + (size_t)wd_t * CE : (wd_t == 9 ? b1 : bd)) + (wd_i & 3) * 4;
-  auto issue_a = [&](int c) {
+  auto issue_a = [&](int c) __attribute__((always_inline)) {
     const int c2 = (c + 2) % NCH, c1 = (c + 1) % NCH;
     float* w1b = sW + (c & 1) * G::WBUF + G::wW1 + wave * G::W1Q;
     float* w2b = sW + ((c + 1) & 1) * G::WBUF + G::wW2 + wave * G::W2Q;
@@ -211,7 +232,7 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
       if (G::L1 == 64 || lane < G::L1) dma16(w1, (unsigned)CE * CIN * 4, w1b + j * 256, voffW1[j], c2 * CC * CIN * 4);
     if (G::L2 == 64 || lane < G::L2) dma16(w2, (unsigned)COUT * CE * 4, w2b, voffW2, c1 * CC * 4);
   };
-  auto issue_b = [&](int c) {
+  auto issue_b = [&](int c) __attribute__((always_inline)) {
     const int c2 = (c + 2) % NCH;
     if (lane < 11)
       __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(wd_src + c2 * CC),
@@ -219,8 +240,6 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
   };
   constexpr int FLIGHT = G::NA + G::NBI;       // requests of this wave that may stay in flight across a counted wait
 
-  // carried rows: wave 0 copies E rows NEW .. IH-1 of a chunk into the chunk's carry slot (this lane's pieces)
-  constexpr int CPL = (G::CSTR / 4 + 63) / 64;
   // UPS: per-lane x taps of the bilinear x2 upsample (align_corners=True) are step-invariant
   const int Hl = H >> 1, Wl = W >> 1;
   const float ups_sy = UPS ? (float)(Hl - 1) / (float)(H - 1) : 0.f, ups_sx = UPS ? (float)(Wl - 1) / (float)(W - 1) : 0.f;
@@ -243,6 +262,7 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();   // the first chunk's weights have landed for everyone (later steps: issued and awaited one chunk ahead)
   bool first = true;
+  int rot = 0;        // carry-slot rotation: chunk c of this step reads slot (c - rot), writes (c - 1 - rot) mod NSLOT
 
 #pragma unroll 1
   for (long long u = u0; u < u1; ++u) {
@@ -258,7 +278,7 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
 
     // ---- A fragments of this step's new halo rows: HBM -> registers ----
     f32x4 fa[G::MT1][G::KG];
-    bool okm[G::MT1];
+    int okm = 0;        // bit i: slot i of this lane is a pixel inside the image
 #pragma unroll
     for (int i = 0; i < G::MT1; ++i) {
       const bool slot_on = i < G::NB || has_x;
@@ -267,7 +287,7 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
         const int iy = iy0 + s_ry[i], ix = ix0 + s_hx[i];
         ok = ok && iy >= 0 && iy < H && ix >= 0 && ix < W;
       }
-      okm[i] = ok;
+      okm |= ok ? 1 << i : 0;
       if (!slot_on) continue;      // wave-uniform
       if constexpr (UPS) {
         // same arithmetic as upsample2x_kernel / ATen: src = dst*(in-1)/(out-1), l1 = frac, l0 = 1-l1
@@ -310,12 +330,9 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
       }
     }
 
-    f32x4 acc3[G::MT3][G::NT3];
+    f32x4 acc3[G::MAXU], xres[RES ? G::MAXU : 1];   // this wave's project-GEMM units (P3Map), the residual input of each
 #pragma unroll
-    for (int i = 0; i < G::MT3; ++i)
-#pragma unroll
-      for (int n = 0; n < G::NT3; ++n) acc3[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 xres[G::MT3][G::NT3];
+    for (int j = 0; j < G::MAXU; ++j) acc3[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (stamps) {
       asm volatile("s_waitcnt vmcnt(0)" ::"v"(fa[0][0]) : "memory");   // the prologue ends when the fragments are in
       mark(0);
@@ -324,11 +341,17 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
       const float* wb = sW + (ch & 1) * G::WBUF;
+      int rslot = ch - rot;
+      rslot += rslot < 0 ? G::NSLOT : 0;
+      const int wslot = rslot == 0 ? G::NSLOT - 1 : rslot - 1;
+      // float offsets in smem (integers, so that every access below stays an LDS access for the compiler):
+      const int oNew = G::oC + wslot * G::CSTR;       // rows NEW .. IH-1 of this chunk: written by P1, read by this P2
+      const int oOld = G::oC + rslot * G::CSTR;       // rows 0 .. KEEP-1: what the step above wrote for this chunk
       // ---- P1: expand GEMM over the new halo rows (weights = MFMA A operand, pixels = B operand: a lane ends up
       //      with 4 consecutive channels of one pixel -> one 16-B LDS store per tile).  Bias = initial accumulator.
       {
         const f32x4 bias = *reinterpret_cast<const f32x4*>(wb + G::wB + 4 * q);
-        auto p1 = [&](auto ns_c) {
+        auto p1 = [&](auto ns_c) __attribute__((always_inline)) {
           constexpr int NS = decltype(ns_c)::value;
           f32x4 acc[NS];
 #pragma unroll
@@ -345,11 +368,12 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
 #pragma unroll
             for (int i = 0; i < NS; ++i)
               if (i < G::NB || x_live)
-                *reinterpret_cast<f32x4*>(sE + ewr[i]) = okm[i] ? lrelu4(acc[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(smem + ewr[i] + ((ecar >> i) & 1 ? oNew : 0)) =
+                    (okm >> i) & 1 ? lrelu4(acc[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
           } else {
 #pragma unroll
             for (int i = 0; i < NS; ++i)
-              if (i < G::NB || x_live) *reinterpret_cast<f32x4*>(sE + ewr[i]) = lrelu4(acc[i]);
+              if (i < G::NB || x_live) *reinterpret_cast<f32x4*>(smem + ewr[i] + ((ecar >> i) & 1 ? oNew : 0)) = lrelu4(acc[i]);
           }
         };
         if (has_x) p1(std::integral_constant<int, G::MT1>{});
@@ -359,89 +383,118 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
       __syncthreads();     // E complete; every wave is done with the previous chunk's P3; Wd visible
       mark(1);
       issue_a(ch);
-      if (res && ch == NCH - 1) {      // residual input in the accumulator layout, in flight under P2 / P3
+      if (RES && ch == NCH - 1) {      // residual input in the accumulator layout, in flight under P2 / P3
+        const int u_lo = wave == 0 ? G::ustart(0) : wave == 1 ? G::ustart(1) : wave == 2 ? G::ustart(2) : G::ustart(3);
+        const int u_n = wave == 0 ? G::ucount(0) : wave == 1 ? G::ucount(1) : wave == 2 ? G::ucount(2) : G::ucount(3);
 #pragma unroll
-        for (int i = 0; i < G::MT3; ++i)
-#pragma unroll
-          for (int n = 0; n < G::NT3; ++n) xres[i][n] = *reinterpret_cast<const f32x4*>(inb + (unsigned)voffX[i] + 16 * n);
+        for (int j = 0; j < G::MAXU; ++j)
+          if (j < u_n) {
+            const int t = (u_lo + j) / G::NT3, n = (u_lo + j) % G::NT3;
+            // the block input at the output pixel: halo pixel (t + 1, l15 + 1)
+            xres[j] = *reinterpret_cast<const f32x4*>(inb + (size_t)(t + 1) * W * ld_in + (unsigned)((l15 + 1) * ld_in + 4 * q) + 16 * n);
+          }
       }
 
-      // ---- P2: depthwise 3x3 over E -> D.  Rows the step did not expand (wave 0, rows < KEEP) come from the
-      //      chunk's carry slot; afterwards wave 0 refreshes the slot with this step's last rows.
+      // ---- P2: depthwise 3x3 over E -> D.  The tap rows of a wave are rows p2_row0 .. of the expanded tile: wave 0's
+      //      first KEEP rows are the carried ones (the chunk's old slot; E itself in a fresh step), wave 3's last KEEP
+      //      rows are the ones P1 has just put into the new slot, everything else is E.
       {
-        const bool use_carry = wave == 0 && !fresh;
-        const int cdelta = G::oC + ch * G::CSTR - G::oE;
         const float* wq = wb + p2_c4;
         const f32x4 bv = *reinterpret_cast<const f32x4*>(wq + G::wB + CC);
         f32x4 a[G::NPX];
 #pragma unroll
         for (int j = 0; j < G::NPX; ++j) a[j] = bv;
+        auto taps = [&](auto lo_c, auto hi_c) __attribute__((always_inline)) {
+          constexpr bool LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {   // one tap column at a time: only three weight vectors live
-          f32x4 wt[3];
+          for (int kx = 0; kx < 3; ++kx) {   // one tap column at a time: only three weight vectors live
+            f32x4 wt[3];
 #pragma unroll
-          for (int ky = 0; ky < 3; ++ky) wt[ky] = *reinterpret_cast<const f32x4*>(wq + G::wWd + (ky * 3 + kx) * CC);
-          const float* e0 = sE + ebk[kx];
-          const float* c0 = use_carry ? e0 + cdelta : e0;
-          f32x4 e[G::NROW];      // all tap rows of the column in flight before the first multiply
+            for (int ky = 0; ky < 3; ++ky) wt[ky] = *reinterpret_cast<const f32x4*>(wq + G::wWd + (ky * 3 + kx) * CC);
+            const float* e0 = smem + (G::oE + ebk[kx]);
+            // (the same tap column, re-based from E row p2_row0 to row 0 of a slot)
+            [[maybe_unused]] const float* l0 = smem + (oOld - p2_row0 * EROW + ebk[kx]);
+            [[maybe_unused]] const float* h0 = smem + (oNew - p2_row0 * EROW + ebk[kx]);
+            f32x4 e[G::NROW];      // all tap rows of the column in flight before the first multiply
 #pragma unroll
-          for (int r = 0; r < G::NROW; ++r) e[r] = *reinterpret_cast<const f32x4*>((r < G::KEEP ? c0 : e0) + r * EROW);
+            for (int r = 0; r < G::NROW; ++r) {
+              if (LO && r < G::KEEP) e[r] = *reinterpret_cast<const f32x4*>(l0 + r * EROW);
+              else if (HI && r >= G::NROW - G::KEEP) e[r] = *reinterpret_cast<const f32x4*>(h0 + (r - (G::NROW - G::KEEP)) * EROW);
+              else e[r] = *reinterpret_cast<const f32x4*>(e0 + r * EROW);
+            }
 #pragma unroll
-          for (int r = 0; r < G::NROW; ++r) {
+            for (int r = 0; r < G::NROW; ++r) {
 #pragma unroll
-            for (int j = 0; j < G::NPX; ++j) {
-              const int ky = r - j * STRIDE;
-              if (ky >= 0 && ky < 3) a[j] += e[r] * wt[ky];
+              for (int j = 0; j < G::NPX; ++j) {
+                const int ky = r - j * STRIDE;
+                if (ky >= 0 && ky < 3) a[j] += e[r] * wt[ky];
+              }
             }
           }
-        }
+        };
+        if (wave == 0 && !fresh) taps(std::true_type{}, std::false_type{});
+        else if (wave == 3) taps(std::false_type{}, std::true_type{});
+        else taps(std::false_type{}, std::false_type{});
 #pragma unroll
-        for (int j = 0; j < G::NPX; ++j) *reinterpret_cast<f32x4*>(sD + dwr[j]) = lrelu4(a[j]);
-        if (wave == 0 && sy + 1 < NSY) {   // (the reads above are done: LDS operations of a wave complete in order)
-#pragma unroll
-          for (int r = 0; r < CPL; ++r) {
-            const int idx = lane + 64 * r;
-            if (CPL * 64 == G::CSTR / 4 || idx < G::CSTR / 4)
-              *reinterpret_cast<f32x4*>(sC + ch * G::CSTR + 4 * idx) =
-                  *reinterpret_cast<const f32x4*>(sE + G::NEW * EROW + 4 * idx);
-          }
-        }
+        for (int j = 0; j < G::NPX; ++j) *reinterpret_cast<f32x4*>(sD + dwr0 + 256 * j) = lrelu4(a[j]);
       }
       wait_vm<FLIGHT>();   // this wave's share of group A of the previous chunk: W2 of this chunk, W1 of the next
       __syncthreads();     // D complete, those weights visible
       mark(2);
       issue_b(ch);
 
-      // ---- P3: project GEMM, acc3[pixel][cout] += D[pixel][CC] x W2c^T (W2c = A operand, pixels = B operand) ----
+      // ---- P3: project GEMM, acc3[unit] += D[pixel tile][CC] x W2c[channel tile]^T (W2c = A operand, pixels = B
+      //      operand); this wave's units, compile-time per wave (P3Map) ----
       {
-        f32x4 fd[G::MT3], fw[G::NT3];
+        auto p3 = [&](auto w_c) __attribute__((always_inline)) {
+          constexpr int WV = decltype(w_c)::value, U0 = G::ustart(WV), UN = G::ucount(WV);
+          if constexpr (UN > 0) {
+            constexpr int T0 = U0 / G::NT3, T1 = (U0 + UN - 1) / G::NT3;
+            f32x4 fd[T1 - T0 + 1], fw[G::NT3];
 #pragma unroll
-        for (int i = 0; i < G::MT3; ++i) fd[i] = *reinterpret_cast<const f32x4*>(sD + dfr[i]);
+            for (int t = T0; t <= T1; ++t) fd[t - T0] = *reinterpret_cast<const f32x4*>(sD + dfr0 + 256 * t);
 #pragma unroll
-        for (int n = 0; n < G::NT3; ++n) fw[n] = *reinterpret_cast<const f32x4*>(wb + w2fr + 256 * n);
+            for (int n = 0; n < G::NT3; ++n)
+              if (UN >= G::NT3 || (U0 % G::NT3 <= n && n <= (U0 + UN - 1) % G::NT3) || (U0 + UN - 1) / G::NT3 > U0 / G::NT3)
+                fw[n] = *reinterpret_cast<const f32x4*>(wb + w2fr + 256 * n);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-          for (int i = 0; i < G::MT3; ++i)
-#pragma unroll
-            for (int n = 0; n < G::NT3; ++n) acc3[i][n] = mfma16(fw[n][s], fd[i][s], acc3[i][n]);
+              for (int j = 0; j < UN; ++j)
+                acc3[j] = mfma16(fw[(U0 + j) % G::NT3][s4], fd[(U0 + j) / G::NT3 - T0][s4], acc3[j]);
+          }
+        };
+        if (wave == 0) p3(std::integral_constant<int, 0>{});
+        else if (wave == 1) p3(std::integral_constant<int, 1>{});
+        else if (wave == 2) p3(std::integral_constant<int, 2>{});
+        else p3(std::integral_constant<int, 3>{});
       }
       // no barrier here: the next P1 writes E only, which nobody reads until after its barrier
-      if (stamps) asm volatile("s_nop 0" ::"v"(acc3[0][0]));   // keep P3's MFMAs in front of the stamp
+      if (stamps) asm volatile("s_nop 0" ::"v"(acc3[0]));   // keep P3's MFMAs in front of the stamp
       mark(3);
     }
 
     // ---- epilogue: + b2, LReLU (+ x), straight from the accumulator layout: 64-B row pieces per pixel ----
+    {
+      auto epi = [&](auto w_c) __attribute__((always_inline)) {
+        constexpr int WV = decltype(w_c)::value, U0 = G::ustart(WV), UN = G::ucount(WV);
 #pragma unroll
-    for (int n = 0; n < G::NT3; ++n) {
-      const f32x4 bias = *reinterpret_cast<const f32x4*>(b2 + 16 * n + 4 * q);
-#pragma unroll
-      for (int i = 0; i < G::MT3; ++i) {
-        f32x4 v = lrelu4(acc3[i][n] + bias);
-        if (res) v += xres[i][n];
-        *reinterpret_cast<f32x4*>(outb + (unsigned)voffO[i] + 16 * n) = v;
-      }
+        for (int j = 0; j < UN; ++j) {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int t = (U0 + j) / G::NT3, n = (U0 + j) % G::NT3;
+          const f32x4 bias = *reinterpret_cast<const f32x4*>(b2 + 16 * n + 4 * q);
+          f32x4 v = lrelu4(acc3[j] + bias);
+          if constexpr (RES) v += xres[j];
+          *reinterpret_cast<f32x4*>(outb + (size_t)t * Wo * ld_out + (unsigned)laneO + 16 * n) = v;
+        }
+      };
+      if (wave == 0) epi(std::integral_constant<int, 0>{});
+      else if (wave == 1) epi(std::integral_constant<int, 1>{});
+      else if (wave == 2) epi(std::integral_constant<int, 2>{});
+      else epi(std::integral_constant<int, 3>{});
     }
+    rot = rot + 1 == G::NSLOT ? 0 : rot + 1;
 
     if (stamps) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -486,7 +539,8 @@ int launch_stream(const float* lo, int ld_lo, int c_lo, const float* in, int ld_
 }  // namespace
 
 // Shapes the streaming kernel takes (everything else: ir_fused.hip): fp32, whole steps, and enough of them.
-bool ir_stream_supported(int cin, int cout, int stride, int h, int w, bool ups) {
+bool ir_stream_supported(int cin, int cout, int stride, int h, int w, bool ups, int res) {
+  if ((res != 0) != (cin == cout && stride == 1)) return false;   // the residual is compiled in or out per instance
   if (h % 8 || w % (16 * stride) || h < 40) return false;
   if (stride != 1) return false;
   if (ups) return cout == 32 && (cin == 64 || cin == 128);
@@ -503,7 +557,7 @@ int launch_ir_stream(const void* lo, int ld_lo, int c_lo, const void* in, int ld
                      const float* wd, const float* bd, const void* w2, const float* b2, void* out, int ld_out,
                      int batch, int h, int w, int cin, int cout, int stride, int res, bool ups, hipStream_t stream) {
   CASYNC_REQUIRE(in && w1 && b1 && wd && bd && w2 && b2 && out && (!ups || lo), "ir_stream: null pointer");
-  CASYNC_REQUIRE(ir_stream_supported(cin, cout, stride, h, w, ups), "ir_stream: no instance for cin=%d cout=%d stride=%d %dx%d",
+  CASYNC_REQUIRE(ir_stream_supported(cin, cout, stride, h, w, ups, res), "ir_stream: no instance for cin=%d cout=%d stride=%d %dx%d",
                  cin, cout, stride, h, w);
   CASYNC_REQUIRE(batch > 0 && ld_in >= cin && ld_in % 4 == 0 && ld_out >= cout && ld_out % 4 == 0, "ir_stream: bad ld");
   CASYNC_REQUIRE(!res || (stride == 1 && cin == cout), "ir_stream: residual needs stride 1 and cin == cout");
