@@ -91,6 +91,7 @@ struct CasyncOptions {
   int ir_stream_stagger = 0; // CASYNC_IR_STREAM_STAGGER: start delay between the workgroups that share a CU, x64 cycles
   int ir_stream_skew = 0;    // CASYNC_IR_STREAM_SKEW: start delay per (workgroup % 16), x64 cycles
   int ir_stream_wgs = 0;     // CASYNC_IR_STREAM_WGS: workgroups per CU of the streaming grid (0 = what fits)
+  int ir_stream_prio = 1;    // CASYNC_IR_STREAM_PRIO: the depthwise (VALU) phase runs at raised wave priority
   int dw_lds = 1;            // CASYNC_DW_LDS: LDS-slab depthwise kernel
   int dw_lds_bytes = 32768;  // CASYNC_DW_LDS_BYTES
   int conv_im2col = 0;       // CASYNC_CONV_IM2COL: dense 3x3 via im2col + GEMM instead of the implicit GEMM

@@ -105,15 +105,16 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
     const float* __restrict__ lo, int ld_lo, int c_lo, const float* __restrict__ in, int ld_in,
     const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ wd,
     const float* __restrict__ bd, const float* __restrict__ w2, const float* __restrict__ b2,
-    float* __restrict__ out, int ld_out, int B, int H, int W, int res, int stagger_a, int stagger_b,
+    float* __restrict__ out, int ld_out, int B, int H, int W, int res, int stagger_a, int stagger_b, int prio,
     unsigned long long* __restrict__ stamps) {
   using G = SGeom<CIN, COUT, STRIDE>;
   constexpr bool RES = CIN == COUT && STRIDE == 1;   // the blocks with a residual connection (module/unet.py:14); the
   (void)res;                                         // launcher sends res != RES to the tile kernel
   // diagnostic only (null in every product call; tools/experiments/ir_timeline.py): shader cycles wave 0 of a
   // workgroup spends in the step prologues / P1 / P2 / P3 (each including the wait or barrier that ends it) / the
-  // step epilogues, summed over its run; word 5 = steps of the run
-  unsigned long long t_mark = stamps ? __builtin_amdgcn_s_memtime() : 0, t_phase[5] = {0, 0, 0, 0, 0};
+  // step epilogues, summed over its run; words 5 / 6 = the waits at barrier 1 / 2 (not part of P1 / P2 here);
+  // word 7 = steps of the run
+  unsigned long long t_mark = stamps ? __builtin_amdgcn_s_memtime() : 0, t_phase[7] = {0, 0, 0, 0, 0, 0, 0};
   auto mark = [&](int slot) __attribute__((always_inline)) {
     if (stamps) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -379,9 +380,15 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
         if (has_x) p1(std::integral_constant<int, G::MT1>{});
         else p1(std::integral_constant<int, G::NB>{});
       }
+      if (stamps) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      mark(1);             // P1 compute (MFMAs, LeakyReLU, E stores)
       wait_vm<FLIGHT>();   // this wave's share of [Wd|b1|bd] of THIS chunk (group B, two chunks ago) has landed
       __syncthreads();     // E complete; every wave is done with the previous chunk's P3; Wd visible
-      mark(1);
+      mark(5);             // ... and the wait for the other waves at barrier 1
+      // P2 is ~60 VALU instructions; beside two other waves' MFMA streams each of them otherwise gets one issue slot
+      // per 32-cycle MFMA and the phase stretches to ~2,000 cycles on the workgroup's critical path.  At raised
+      // priority it issues back to back (the MFMAs it delays are delayed by the few cycles they would pay anyway).
+      if (prio) __builtin_amdgcn_s_setprio(3);
       issue_a(ch);
       if (RES && ch == NCH - 1) {      // residual input in the accumulator layout, in flight under P2 / P3
         const int u_lo = wave == 0 ? G::ustart(0) : wave == 1 ? G::ustart(1) : wave == 2 ? G::ustart(2) : G::ustart(3);
@@ -438,9 +445,12 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
 #pragma unroll
         for (int j = 0; j < G::NPX; ++j) *reinterpret_cast<f32x4*>(sD + dwr0 + 256 * j) = lrelu4(a[j]);
       }
+      if (prio) __builtin_amdgcn_s_setprio(0);
+      if (stamps) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      mark(2);             // P2 compute
       wait_vm<FLIGHT>();   // this wave's share of group A of the previous chunk: W2 of this chunk, W1 of the next
       __syncthreads();     // D complete, those weights visible
-      mark(2);
+      mark(6);             // ... and the wait at barrier 2
       issue_b(ch);
 
       // ---- P3: project GEMM, acc3[unit] += D[pixel tile][CC] x W2c[channel tile]^T (W2c = A operand, pixels = B
@@ -506,8 +516,8 @@ __global__ __launch_bounds__(256, (SGeom<CIN, COUT, STRIDE>::occ)) void ir_strea
     }
   }
   if (stamps && tid == 0 && blockIdx.x < 4096) {
-    for (int k = 0; k < 5; ++k) stamps[(size_t)blockIdx.x * 8 + k] = t_phase[k];
-    stamps[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)(u1 - u0);
+    for (int k = 0; k < 7; ++k) stamps[(size_t)blockIdx.x * 8 + k] = t_phase[k];
+    stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)(u1 - u0);
   }
   wait_vm<0>();   // the weight requests issued ahead of the (non-existent) next chunks still target this workgroup's LDS
 }
@@ -531,20 +541,25 @@ int launch_stream(const float* lo, int ld_lo, int c_lo, const float* in, int ld_
   if (grid >= 16) grid &= ~7ll;      // whole multiples of the eight XCDs (the run -> XCD remap needs it)
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2,
                      out, ld_out, batch, h, w, res, casync_opts().ir_stream_stagger, casync_opts().ir_stream_skew,
-                     casync_ir_stamps());
+                     casync_opts().ir_stream_prio, casync_ir_stamps());
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }
 
 }  // namespace
 
-// Shapes the streaming kernel takes (everything else: ir_fused.hip): fp32, whole steps, and enough of them.
+// Shapes the streaming kernel takes (everything else: ir_fused.hip): fp32, stride 1, whole steps.  It exists for the two
+// block shapes where it beats the tile kernel (measured, profiles/r3_ir_stream_ab.txt): 64 -> 32 (up4's first block,
+// with or without the folded upsample) and 32 -> 32 at 160 x 160 (up4's second block).  For 128 -> 32 and 64 -> 64 the
+// carry slots leave room for two workgroups per CU only and the tile kernel wins; those instances are not built.
+// ir_stream = 2 sends every shape with an instance here (tests: small images).
 bool ir_stream_supported(int cin, int cout, int stride, int h, int w, bool ups, int res) {
   if ((res != 0) != (cin == cout && stride == 1)) return false;   // the residual is compiled in or out per instance
-  if (h % 8 || w % (16 * stride) || h < 40) return false;
-  if (stride != 1) return false;
-  if (ups) return cout == 32 && (cin == 64 || cin == 128);
-  return (cin == 32 && cout == 32) || (cin == 64 && cout == 32) || (cin == 128 && cout == 32) || (cin == 64 && cout == 64);
+  if (stride != 1 || h % 8 || w % 16 || cout != 32) return false;
+  const bool all = casync_opts().ir_stream >= 2;
+  if (cin == 64) return all || h >= 40;
+  if (cin == 32 && !ups) return all || (long long)h * w >= 160 * 160;
+  return false;
 }
 
 const char* ir_stream_kernel_name(int cin, int cout, int stride, bool ups) {
@@ -573,11 +588,8 @@ int launch_ir_stream(const void* lo, int ld_lo, int c_lo, const void* in, int ld
     return launch_stream<CI, CO, S, U>((const float*)lo, ld_lo, c_lo, (const float*)in, ld_in, (const float*)w1, b1, wd, bd, \
                                        (const float*)w2, b2, (float*)out, ld_out, batch, h, w, res, stream);
   S_CASE(64, 32, 1, true)     // up4.ir0
-  S_CASE(128, 32, 1, true)    // up3.ir0
   S_CASE(64, 32, 1, false)
-  S_CASE(128, 32, 1, false)
-  S_CASE(32, 32, 1, false)    // up4.ir1, up3.ir1
-  S_CASE(64, 64, 1, false)    // down1.ir1, up2.ir1
+  S_CASE(32, 32, 1, false)    // up4.ir1
 #undef S_CASE
   casync_set_error("ir_stream: no instance for cin=%d cout=%d stride=%d", cin, cout, stride);
   return CASYNC_ERR_ARG;

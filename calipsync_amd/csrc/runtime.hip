@@ -38,6 +38,7 @@ const OptField kFields[] = {
     {"ir_stream_stagger", &CasyncOptions::ir_stream_stagger},
     {"ir_stream_skew", &CasyncOptions::ir_stream_skew},
     {"ir_stream_wgs", &CasyncOptions::ir_stream_wgs},
+    {"ir_stream_prio", &CasyncOptions::ir_stream_prio},
     {"dw_lds", &CasyncOptions::dw_lds},
     {"dw_lds_bytes", &CasyncOptions::dw_lds_bytes},
     {"conv_im2col", &CasyncOptions::conv_im2col},

@@ -46,8 +46,11 @@ for name, cin, cout, stride, hw in SHAPES:
     raw = stamps.cpu().numpy().reshape(-1, 8)
     raw = raw[raw[:, :5].sum(1) > 0]
     st = raw[:, :5].astype(np.float64)
-    if (raw[:, 5] > 0).all():        # the streaming kernel sums over the steps of a run (word 5): per step
-        st = st / raw[:, 5:6]
+    extra = ""
+    if (raw[:, 7] > 0).all():        # the streaming kernel sums over the steps of a run (word 7): per step
+        st = st / raw[:, 7:8]
+        w = np.median(raw[:, 5:7] / raw[:, 7:8], axis=0) / (ce // 16)
+        extra = f"  [+ barrier-1 wait {w[0]:5.0f}/chunk, barrier-2 wait {w[1]:5.0f}/chunk, not in P1 / P2]"
     med = np.median(st, axis=0)
     tot = med.sum()
     nch = ce // 16
@@ -55,4 +58,4 @@ for name, cin, cout, stride, hw in SHAPES:
     print(f"{name:10s} cin={cin:3d} cout={cout:3d} s={stride} hw={hw:3d}: {ms * 1e3:7.1f} us {flops / ms / 1e9:6.1f} TF | wave-0 cycles per "
           f"workgroup {tot:8.0f}: prologue {med[0]:6.0f} ({100 * med[0] / tot:4.1f}%)  P1 {med[1]:6.0f} ({100 * med[1] / tot:4.1f}%, "
           f"{med[1] / nch:5.0f}/chunk)  P2 {med[2]:6.0f} ({100 * med[2] / tot:4.1f}%, {med[2] / nch:5.0f}/chunk)  P3 {med[3]:6.0f} "
-          f"({100 * med[3] / tot:4.1f}%, {med[3] / nch:5.0f}/chunk)  epilogue {med[4]:6.0f} ({100 * med[4] / tot:4.1f}%)")
+          f"({100 * med[3] / tot:4.1f}%, {med[3] / nch:5.0f}/chunk)  epilogue {med[4]:6.0f} ({100 * med[4] / tot:4.1f}%)" + extra)
