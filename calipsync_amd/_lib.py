@@ -55,6 +55,8 @@ _PROTOS = {
                                     C.c_int, c_f32p, c_f32p, C.c_void_p]),
     "casync_op_dw3x3": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_void_p]),
+    "casync_op_pw_dw": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.c_void_p]),
     "casync_op_ir_fused": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                      c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_void_p]),

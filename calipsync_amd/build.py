@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libcasync_hip.so")
-SOURCES = ["runtime.hip", "gemm.hip", "ops.hip", "ir_fused.hip", "ir_stream.hip", "attention.hip", "frame_ops.hip", "engine.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "ops.hip", "ir_fused.hip", "ir_stream.hip", "pw_dw.hip", "attention.hip", "frame_ops.hip", "engine.hip"]
 HEADERS = ["common.h", "ir_common.h", "gemm_experimental.inc", os.path.join("..", "..", "include", "casync_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # CASYNC_EXPERIMENTAL=1: also compile the kernels that were measured and not adopted (gemm_experimental.inc, deeper GEMM

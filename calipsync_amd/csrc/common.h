@@ -86,6 +86,7 @@ struct CasyncOptions {
   int fuse_up = 1;           // CASYNC_FUSE_UP: bilinear upsample folded into up3/up4
   int fuse_min_hw = 32;      // CASYNC_FUSE_MIN_HW: lowest resolution the fused kernel is used at
   int fuse_q = 1;            // CASYNC_FUSE_Q: query projection as 64 extra columns of the p_1 GEMM
+  int fuse_dw = 1;           // CASYNC_FUSE_DW: expand GEMM + depthwise 3x3 in one kernel below 32x32 (pw_dw.hip), fp32
   int ir_stream = 1;         // CASYNC_IR_STREAM: row-streaming fused block (ir_stream.hip) where its shapes allow, fp32
   int ir_stream_min = 2;     // CASYNC_IR_STREAM_MIN: fewest steps per workgroup run of the streaming kernel
   int ir_stream_stagger = 0; // CASYNC_IR_STREAM_STAGGER: start delay between the workgroups that share a CU, x64 cycles
@@ -227,6 +228,12 @@ int launch_ir_fused(const void* in, int ld_in, const void* w1, const float* b1, 
                     const float* bd, const void* w2, const float* b2, void* out, int ld_out,
                     int batch, int h, int w, int cin, int cout, int stride, int res,
                     hipStream_t stream, int dtype = DT_F32);
+// expand 1x1 + depthwise 3x3 of a low-resolution inverted residual in one kernel (pw_dw.hip): fp32, 10x10 / 16x16 /
+// 20x20 frames; a [frames*hw*hw, lda], w1 [cexp][cin], wd [9][cexp], d [frames*ho*ho, ldd]
+bool pw_dw_supported(int hw, int cin, int cexp, int stride);
+const char* pw_dw_kernel_name(int hw, int cexp, int frames);
+int launch_pw_dw(const void* a, int lda, const void* w1, const float* b1, const float* wd, const float* bd, void* d, int ldd,
+                 int frames, int hw, int stride, int cin, int cexp, hipStream_t stream);
 int launch_im2col3x3(const void* in, void* out, int batch, int h, int wdt, int c, int stride,
                      int pad, hipStream_t stream, int dtype = DT_F32);
 int launch_upsample2x(const void* in, void* out, int ldc, int batch, int h, int wdt, int c,

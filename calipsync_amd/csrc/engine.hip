@@ -421,14 +421,24 @@ struct Plan {
       });
       return;
     }
-    GemmEpilogue ep1;
-    ep1.act = 1;
-    gemm(p + ".pw1", in, ld_in, p + ".pw1.w", e1, b.cexp(), m_in, b.cexp(), b.cin, ep1);
-    r.run((p + ".dw").c_str(), dw3x3_kernel_name(b.hw_in, b.hw_in, b.cexp(), b.stride, dt()),
-          2.0 * 9 * m_out * b.cexp(), dtype_size(dt()) * (double)(m_in + m_out) * b.cexp(), [&] {
-      return launch_dw3x3(e1, e.W(p + ".dw.w"), e.W(p + ".dw.b"), e2, B, b.hw_in, b.hw_in, b.cexp(),
-                          b.stride, r.s, dt());
-    });
+    if (dt() == DT_F32 && o.fuse_dw && pw_dw_supported(b.hw_in, b.cin, b.cexp(), b.stride)) {
+      // expand GEMM whose output tile is whole frames: the depthwise conv runs on the tile in LDS, E never exists
+      r.run((p + ".pw1dw").c_str(), pw_dw_kernel_name(b.hw_in, b.cexp(), B),
+            2.0 * (m_in * (double)b.cin * b.cexp() + 9.0 * m_out * b.cexp()),
+            4.0 * (m_in * (double)b.cin + (double)b.cexp() * b.cin + (double)m_out * b.cexp()), [&] {
+        return launch_pw_dw(in, ld_in, e.W(p + ".pw1.w"), e.W(p + ".pw1.b"), e.W(p + ".dw.w"), e.W(p + ".dw.b"), e2,
+                            b.cexp(), B, b.hw_in, b.stride, b.cin, b.cexp(), r.s);
+      });
+    } else {
+      GemmEpilogue ep1;
+      ep1.act = 1;
+      gemm(p + ".pw1", in, ld_in, p + ".pw1.w", e1, b.cexp(), m_in, b.cexp(), b.cin, ep1);
+      r.run((p + ".dw").c_str(), dw3x3_kernel_name(b.hw_in, b.hw_in, b.cexp(), b.stride, dt()),
+            2.0 * 9 * m_out * b.cexp(), dtype_size(dt()) * (double)(m_in + m_out) * b.cexp(), [&] {
+        return launch_dw3x3(e1, e.W(p + ".dw.w"), e.W(p + ".dw.b"), e2, B, b.hw_in, b.hw_in, b.cexp(),
+                            b.stride, r.s, dt());
+      });
+    }
     GemmEpilogue ep2;
     if (extra) ep2 = *extra;
     ep2.act = 1;
@@ -1054,6 +1064,11 @@ int casync_op_conv3x3(const void* in, const void* w, const float* bias, void* ou
 int casync_op_dw3x3(const void* in, const float* w, const float* bias, void* out, int batch, int h,
                     int wdt, int c, int stride, casync_stream stream) {
   return launch_dw3x3(in, w, bias, out, batch, h, wdt, c, stride, (hipStream_t)stream, g_op_dtype);
+}
+int casync_op_pw_dw(const void* a, int lda, const void* w1, const float* b1, const float* wd, const float* bd, void* d, int ldd,
+                    int frames, int hw, int stride, int cin, int cexp, casync_stream stream) {
+  CASYNC_REQUIRE(g_op_dtype == DT_F32, "pw_dw: fp32 only");
+  return launch_pw_dw(a, lda, w1, b1, wd, bd, d, ldd, frames, hw, stride, cin, cexp, (hipStream_t)stream);
 }
 int casync_op_ir_fused(const void* in, int ld_in, const void* w1, const float* b1, const float* wd,
                        const float* bd, const void* w2, const float* b2, void* out, int ld_out,

@@ -1,0 +1,245 @@
+// Expand 1x1 conv + BN + LeakyReLU + depthwise 3x3 + BN + LeakyReLU in ONE kernel, for the inverted residuals of the
+// low-resolution stages (10x10, 16x16, 20x20: reference module/unet.py:17-30 with BN folded):
+//
+//   D[b, oy, ox, n] = lrelu( sum_taps wd[tap][n] * E[b, oy*s + ky - 1, ox*s + kx - 1, n] + bd[n] ),
+//   E[b, y, x, n]   = lrelu( A[b, y, x, :] . W1[n, :] + b1[n] )                    (zero outside the frame)
+//
+// Below 32x32 the expanded tensor (2 x Cin channels, up to 2048) is too wide for the fully fused block of
+// ir_fused.hip (its project accumulators would not fit the registers), so round 2 ran these blocks as GEMM ->
+// depthwise -> GEMM: 30 depthwise launches per forward, each a serialisation point of its lane (11-14 us alone,
+// 26-49 us beside the other lane's GEMMs: profiles/r2_f32_b64_kernel_stats_timed.csv) and one HBM/L2 round trip
+// of E each.  Here an output tile of the expand GEMM is WHOLE FRAMES x BN channels: the 3x3 neighbourhood of every
+// pixel is inside the tile, so the depthwise conv runs on the accumulator tile while it sits in LDS -- no halo, no
+// recompute, E never leaves the CU.  The project GEMM (pw_gemm) then reads D as before.
+//
+// GEMM part: the LDS-DMA ring of gemm.hip (128-B k-tile rows, XOR-swizzled through the source address, two stages,
+// buffer_load ... lds with per-lane constant offsets and the k position in an SGPR), computed with
+// v_mfma_f32_16x16x4_f32 so that the row count only has to be a multiple of 16: 2 frames of 10x10 = 200 rows -> 208
+// (4 % padding), 16x16 = 256, 20x20 = 400 rows exactly.  The weight fragment is the MFMA A operand and the pixels the
+// B operand: a lane ends up with four consecutive channels of one pixel, one 16-B LDS store per tile.
+//
+// Epilogue: + b1, LeakyReLU -> E tile [pixel][BN] in LDS (over the dead ring; 16-B columns XOR-keyed by the pixel so the
+// stores of eight consecutive pixels spread over the banks) -> every thread owns one channel quad (its nine tap
+// weights live in registers) and walks output pixels: nine 16-B LDS reads, nine packed FMAs, LeakyReLU, one coalesced
+// 16-B store of D.
+#include <stdlib.h>
+
+#include "common.h"
+#include "ir_common.h"
+
+namespace {
+
+constexpr int ROWB = 128;   // bytes of one k-tile row (32 floats)
+
+template <int HW, int F, int BN>
+struct FTGeom {
+  static constexpr int P = HW * HW, M = F * P, MT = (M + 15) / 16, M_PAD = 16 * MT;
+  static constexpr int NT = BN / 16, WPN = 4 / NT;             // n-tiles; waves that share an n-tile
+  static constexpr int MTW = (MT + WPN - 1) / WPN;             // m-tiles per wave
+  static constexpr int ROWS = M_PAD + BN, LPT = (ROWS + 31) / 32, STAGE = LPT * 32 * ROWB;
+  static constexpr int NQ = BN / 4, PSTEP = 256 / NQ;          // channel quads; pixels a pass of the epilogue covers
+  static constexpr size_t etile = (size_t)M_PAD * BN * sizeof(float);
+  static constexpr size_t lds = 2 * (size_t)STAGE > etile ? 2 * (size_t)STAGE : etile;
+  static constexpr int occ = (int)(160 * 1024 / lds) >= 2 ? 2 : 1;
+  static_assert(NT == 2 || NT == 4, "BN = 32 or 64");
+  static_assert(lds <= 160 * 1024, "LDS budget");
+};
+
+__device__ __forceinline__ void ft_dma16(const void* base, unsigned bytes, void* lds, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000),
+                                           (void __attribute__((address_space(3)))*)lds, 16, voff, soff, 0, 0);
+#endif
+}
+
+template <int HW, int F, int BN>
+__global__ __launch_bounds__(256, (FTGeom<HW, F, BN>::occ)) void pw_dw_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ W1, const float* __restrict__ b1,
+    const float* __restrict__ wd, const float* __restrict__ bd, float* __restrict__ D, int ldd, int frames, int K, int N,
+    int stride, int n_ntiles, int nwg, unsigned a_bytes, unsigned w_bytes) {
+  using G = FTGeom<HW, F, BN>;
+  extern __shared__ __attribute__((aligned(16))) char ring[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4, lrow8 = lane >> 3, lcol = lane & 7;
+
+  // XCD-aware tile order (speed only): workgroups b, b + 8, ... share an XCD; give each XCD a contiguous run of tiles so
+  // the channel tiles of one frame group (same A rows) meet in one L2
+  int ft, nt;
+  {
+    const int t = blockIdx.x, qn = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
+    const int bid = (xcd < r ? xcd * (qn + 1) : r * (qn + 1) + (xcd - r) * qn) + idx;
+    ft = bid / n_ntiles;
+    nt = bid - ft * n_ntiles;
+  }
+  const int f0 = ft * F, nf = frames - f0 < F ? frames - f0 : F;   // frames of this tile
+  const int m0 = f0 * G::P, m_valid = nf * G::P, n0 = nt * BN;
+  const int nk = K / 32;
+
+  // ---- LDS-DMA: this lane's source offset of each of the wave's LPT instructions (8 rows x 128 B each) ----
+  int voff[G::LPT];
+#pragma unroll
+  for (int j = 0; j < G::LPT; ++j) {
+    const int r = (j * 4 + wave) * 8 + lrow8;              // row inside the stage: [0, M_PAD) = A, then BN rows of W1
+    const int cs = lcol ^ ((r >> 1) & 7);                  // swizzled source column
+    if ((j * 4 + wave) * 8 < G::M_PAD) {
+      const int row = m0 + (r < m_valid ? r : m_valid - 1);   // pad rows re-read the last pixel; never used
+      voff[j] = (int)((long long)row * lda * 4) + cs * 16;
+    } else {
+      const int wr = r - G::M_PAD < BN ? r - G::M_PAD : 0;    // rows behind the tile (LPT rounds up) re-read W row 0
+      voff[j] = (n0 + wr) * K * 4 + cs * 16;
+    }
+  }
+  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < G::LPT; ++j) {
+      char* dst = ring + stage * G::STAGE + (j * 4 + wave) * 8 * ROWB;
+      if ((j * 4 + wave) * 8 < G::M_PAD) ft_dma16(A, a_bytes, dst, voff[j], kt * ROWB);
+      else ft_dma16(W1, w_bytes, dst, voff[j], kt * ROWB);
+    }
+  };
+
+  // ---- MFMA: wave -> channel tile `wn` and the pixel tiles wm, wm + WPN, ... ----
+  const int wn = wave % G::NT, wm = wave / G::NT;
+  const int key = (l15 >> 1) & 7;                          // (row >> 1) & 7 of every fragment row 16 t + l15
+  const int frag0 = l15 * ROWB + ((q ^ key) << 4), frag1 = l15 * ROWB + (((4 + q) ^ key) << 4);   // k-groups 0 / 1
+  f32x4 acc[G::MTW];
+#pragma unroll
+  for (int i = 0; i < G::MTW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of k-tile kt has landed
+    __syncthreads();                                   // ... everyone's; and everyone is done reading the other stage
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    const char* st = ring + (kt & 1) * G::STAGE;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int fo = g ? frag1 : frag0;
+      const f32x4 fw = *reinterpret_cast<const f32x4*>(st + (G::M_PAD + 16 * wn) * ROWB + fo);
+      // two pixel tiles at a time: consecutive MFMAs never wait for their own accumulator
+#pragma unroll
+      for (int i = 0; i < G::MTW; i += 2) {
+        const bool two = i + 1 < G::MTW;
+        const int t0 = wm + G::WPN * i, t1 = wm + G::WPN * (i + 1);
+        if (t0 < G::MT) {
+          const f32x4 fa0 = *reinterpret_cast<const f32x4*>(st + 16 * t0 * ROWB + fo);
+          f32x4 fa1 = fa0;
+          const bool on1 = two && t1 < G::MT;
+          if (on1) fa1 = *reinterpret_cast<const f32x4*>(st + 16 * t1 * ROWB + fo);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            acc[i] = mfma16(fw[s], fa0[s], acc[i]);
+            if (on1) acc[i + 1] = mfma16(fw[s], fa1[s], acc[i + 1]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();   // the ring is consumed: it becomes the E tile
+
+  // ---- epilogue 1: + b1, LeakyReLU -> E[pixel][BN] (16-B column XOR pixel & 7) ----
+  float* sE = reinterpret_cast<float*>(ring);
+  {
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(b1 + n0 + 16 * wn + 4 * q);
+#pragma unroll
+    for (int i = 0; i < G::MTW; ++i) {
+      const int t = wm + G::WPN * i;
+      if (t < G::MT) {
+        const int px = 16 * t + l15;
+        *reinterpret_cast<f32x4*>(sE + px * BN + (((4 * wn + q) ^ (px & 7)) << 2)) = lrelu4(acc[i] + bias);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue 2: depthwise 3x3 (zero padding), + bd, LeakyReLU -> D ----
+  {
+    const int cq = tid % G::NQ, p_first = tid / G::NQ;
+    const int ho = (HW + 2 - 3) / stride + 1, pout = ho * ho;
+    const float* wq = wd + n0 + 4 * cq;
+    f32x4 wt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(wq + (size_t)t * N);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bd + n0 + 4 * cq);
+    float* dq = D + (size_t)f0 * pout * ldd + n0 + 4 * cq;
+    const int total = nf * pout;
+    for (int po = p_first; po < total; po += G::PSTEP) {
+      const int f = po / pout, rem = po - f * pout;
+      const int oy = rem / ho, ox = rem - oy * ho;
+      const int iy0 = oy * stride - 1, ix0 = ox * stride - 1;
+      f32x4 a = bv;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = iy0 + ky;
+        if (iy < 0 || iy >= HW) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = ix0 + kx;
+          if (ix < 0 || ix >= HW) continue;
+          const int px = f * G::P + iy * HW + ix;
+          a += *reinterpret_cast<const f32x4*>(sE + px * BN + ((cq ^ (px & 7)) << 2)) * wt[ky * 3 + kx];
+        }
+      }
+      *reinterpret_cast<f32x4*>(dq + (size_t)po * ldd) = lrelu4(a);
+    }
+  }
+}
+
+template <int HW, int F, int BN>
+int launch_ft(const float* a, int lda, const float* w1, const float* b1, const float* wd, const float* bd, float* d, int ldd,
+              int frames, int k, int n, int stride, hipStream_t stream) {
+  using G = FTGeom<HW, F, BN>;
+  auto kern = pw_dw_kernel<HW, F, BN>;
+  static unsigned long long attr_once = 0;
+  if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)G::lds)) return st;
+  const int n_ft = (frames + F - 1) / F, n_nt = n / BN;
+  const long long nwg = (long long)n_ft * n_nt;
+  const unsigned long long ab = ((unsigned long long)((long long)frames * G::P - 1) * lda + k) * 4, wb = (unsigned long long)n * k * 4;
+  CASYNC_REQUIRE(nwg < (1ll << 31) && ab < (1ull << 31) && wb < (1ull << 31), "pw_dw: operand larger than 2 GiB");
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), G::lds, stream, a, lda, w1, b1, wd, bd, d, ldd, frames, k, n, stride,
+                     n_nt, (int)nwg, (unsigned)ab, (unsigned)wb);
+  CASYNC_CHECK_HIP(hipGetLastError());
+  return CASYNC_OK;
+}
+
+// channel-tile width: 64 unless that leaves the chip half empty (the launch then has < 256 workgroups)
+inline int ft_bn(int hw, int n, int frames) {
+  if (hw == 20) return 32;
+  const long long ft = hw == 10 ? (frames + 1) / 2 : frames;
+  return n % 64 == 0 && ft * (n / 64) >= 256 ? 64 : 32;
+}
+
+}  // namespace
+
+bool pw_dw_supported(int hw, int cin, int cexp, int stride) {
+  if (cin % 32 || cexp % 64) return false;
+  if (hw == 10 || hw == 16) return stride == 1;
+  return hw == 20 && (stride == 1 || stride == 2);
+}
+
+const char* pw_dw_kernel_name(int hw, int cexp, int frames) {
+  static thread_local char buf[64];
+  const int bn = hw == 16 ? 64 : ft_bn(hw, cexp, frames);
+  snprintf(buf, sizeof(buf), "pw_dw_kernel<%d, %d, %d>", hw, hw == 10 ? 2 : 1, bn);
+  return buf;
+}
+
+int launch_pw_dw(const void* a, int lda, const void* w1, const float* b1, const float* wd, const float* bd, void* d, int ldd,
+                 int frames, int hw, int stride, int cin, int cexp, hipStream_t stream) {
+  CASYNC_REQUIRE(a && w1 && b1 && wd && bd && d && frames > 0, "pw_dw: bad args");
+  CASYNC_REQUIRE(pw_dw_supported(hw, cin, cexp, stride), "pw_dw: no instance for %dx%d cin=%d cexp=%d stride=%d", hw, hw, cin, cexp,
+                 stride);
+  CASYNC_REQUIRE(lda >= cin && lda % 4 == 0 && ldd >= cexp && ldd % 4 == 0, "pw_dw: bad leading dimensions");
+  CASYNC_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)w1 % 16) == 0 && ((uintptr_t)d % 16) == 0 && ((uintptr_t)b1 % 16) == 0 &&
+                     ((uintptr_t)wd % 16) == 0 && ((uintptr_t)bd % 16) == 0,
+                 "pw_dw: pointers must be 16-B aligned");
+  const float* af = static_cast<const float*>(a);
+  const float* wf = static_cast<const float*>(w1);
+  float* df = static_cast<float*>(d);
+  if (hw == 10)
+    return ft_bn(hw, cexp, frames) == 64 ? launch_ft<10, 2, 64>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, stream)
+                                         : launch_ft<10, 2, 32>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, stream);
+  if (hw == 16) return launch_ft<16, 1, 64>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, stream);
+  return launch_ft<20, 1, 32>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, stream);
+}

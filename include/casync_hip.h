@@ -168,6 +168,12 @@ int casync_op_conv3x3(const void* in, const void* w, const float* bias, void* ou
  * w is tap-major [9][C].                                                    */
 int casync_op_dw3x3(const void* in, const float* w, const float* bias, void* out,
                     int batch, int h, int wdt, int c, int stride, casync_stream stream);
+/* Expand 1x1 conv + BN + LeakyReLU + depthwise 3x3 (pad 1, stride 1|2) + BN + LeakyReLU in one kernel, fp32, for the
+ * inverted residuals below 32x32 (module/unet.py:17-30): the GEMM's output tile is whole frames, the depthwise conv
+ * runs on it in LDS.  a [frames*hw*hw, lda], w1 [cexp][cin], b1 [cexp], wd [9][cexp] tap-major, bd [cexp],
+ * d [frames*ho*ho, ldd].  hw in {10, 16, 20} (stride 2 only at 20), cin % 32 == 0, cexp % 64 == 0.           */
+int casync_op_pw_dw(const void* a, int lda, const void* w1, const float* b1, const float* wd, const float* bd,
+                    void* d, int ldd, int frames, int hw, int stride, int cin, int cexp, casync_stream stream);
 /* Whole inverted-residual block in one kernel (expanded tensor stays in LDS); the
  * high-resolution stages use it.  Replaces InvertedResidual.forward
  * (module/unet.py:16-40) with BN folded: w1 [2cin][cin], wd [9][2cin], w2 [cout][2cin]

@@ -355,6 +355,35 @@ def test_ir_fused_with_upsample(lib, recipe_sd, prefix, cin, h):
     assert rel_err(nchw(out), ref) < 5e-6
 
 
+@pytest.mark.parametrize("hw,stride,cin,cexp,frames", [
+    (10, 1, 512, 1024, 5), (10, 1, 1024, 2048, 2), (10, 1, 256, 512, 33), (16, 1, 256, 512, 3), (20, 1, 256, 512, 2),
+    (20, 2, 256, 512, 3), (20, 1, 128, 256, 2), (10, 1, 64, 128, 1)])
+def test_pw_dw_fused(lib, hw, stride, cin, cexp, frames):
+    """Expand 1x1 + LeakyReLU + depthwise 3x3 + LeakyReLU in one kernel (pw_dw.hip) vs plain PyTorch: odd frame
+    counts (a half-empty frame pair), both channel-tile widths, stride 2, strided operands."""
+    g = torch.Generator().manual_seed(hw * 100 + cin + frames)
+    x = torch.randn(frames, cin, hw, hw, generator=g)
+    w1 = torch.randn(cexp, cin, generator=g) / cin ** 0.5
+    b1 = torch.randn(cexp, generator=g) * 0.3
+    wd = torch.randn(cexp, 1, 3, 3, generator=g) / 3
+    bd = torch.randn(cexp, generator=g) * 0.3
+    e = F.leaky_relu(F.conv2d(x.double(), w1.double()[:, :, None, None], b1.double()), 0.01)
+    ref = F.leaky_relu(F.conv2d(e, wd.double(), bd.double(), stride, 1, 1, cexp), 0.01).float()
+    ho = ref.shape[2]
+    lda, ldd = cin + 32, cexp + 16
+    xin = torch.full((frames, hw, hw, lda), 5.0)
+    xin[..., 32:] = x.permute(0, 2, 3, 1)
+    xin = xin.to(dev())
+    out = torch.full((frames, ho, ho, ldd), -7.0, device=dev())
+    wdp = wd.reshape(cexp, 9).T.contiguous().to(dev())          # tap-major [9][C]
+    w1d, b1d, bdd = w1.to(dev()), b1.to(dev()), bd.to(dev())
+    ok(lib.casync_op_pw_dw(xin.data_ptr() + 32 * 4, lda, ptr(w1d), ptr(b1d), ptr(wdp), ptr(bdd), out.data_ptr() + 16 * 4, ldd,
+                           frames, hw, stride, cin, cexp, stream()))
+    o = out.cpu()
+    assert (o[..., :16] == -7).all()
+    assert rel_err(o[..., 16:].permute(0, 3, 1, 2), ref) < 3e-6
+
+
 STREAM_CASES = [  # (state_dict prefix, cin, cout, res, ups, h, w, batch): the instances ir_stream.hip builds
     ("up4.conv.double_conv.0", 64, 32, False, False, 48, 32, 3),
     ("up4.conv.double_conv.0", 64, 32, False, True, 48, 32, 3),
