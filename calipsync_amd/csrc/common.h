@@ -87,7 +87,8 @@ struct CasyncOptions {
   int fuse_min_hw = 32;      // CASYNC_FUSE_MIN_HW: lowest resolution the fused kernel is used at
   int fuse_q = 1;            // CASYNC_FUSE_Q: query projection as 64 extra columns of the p_1 GEMM
   int fuse_dw = 1;           // CASYNC_FUSE_DW: expand GEMM + depthwise 3x3 in one kernel below 32x32 (pw_dw.hip), fp32
-  int ir_stream = 1;         // CASYNC_IR_STREAM: row-streaming fused block (ir_stream.hip) where its shapes allow, fp32
+  int ir_stream = 0;         // CASYNC_IR_STREAM: row-streaming fused block (ir_stream.hip; experimental builds only): 1 = where
+                             //   it beats the tile kernel in isolation, 2 = every shape it has an instance for
   int ir_stream_min = 2;     // CASYNC_IR_STREAM_MIN: fewest steps per workgroup run of the streaming kernel
   int ir_stream_stagger = 0; // CASYNC_IR_STREAM_STAGGER: start delay between the workgroups that share a CU, x64 cycles
   int ir_stream_skew = 0;    // CASYNC_IR_STREAM_SKEW: start delay per (workgroup % 16), x64 cycles

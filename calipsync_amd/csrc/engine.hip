@@ -421,7 +421,8 @@ struct Plan {
       });
       return;
     }
-    if (dt() == DT_F32 && o.fuse_dw && pw_dw_supported(b.hw_in, b.cin, b.cexp(), b.stride)) {
+    // (from 16 frames per launch: below that its whole-frame tiles are too few to fill the chip -- B=1 0.92 vs 0.82 ms)
+    if (dt() == DT_F32 && o.fuse_dw && B >= 16 && pw_dw_supported(b.hw_in, b.cin, b.cexp(), b.stride)) {
       // expand GEMM whose output tile is whole frames: the depthwise conv runs on the tile in LDS, E never exists
       r.run((p + ".pw1dw").c_str(), pw_dw_kernel_name(b.hw_in, b.cexp(), B),
             2.0 * (m_in * (double)b.cin * b.cexp() + 9.0 * m_out * b.cexp()),
@@ -675,10 +676,10 @@ int casync_set_option(casync_handle h, const char* name, int value) {
   const int st = casync_option_ref(h ? h->opt : casync_default_options(), name, &slot);
   if (st != CASYNC_OK) return st;
 #ifndef CASYNC_EXPERIMENTAL
-  // switches of kernels that are not in this build (measured and not adopted: gemm_experimental.inc, im2col, the
-  // deeper rings, the experimental tile shapes) can only be set to "off"
+  // switches of kernels that are not in this build (measured and not adopted: gemm_experimental.inc, ir_stream.hip,
+  // im2col, the deeper rings, the experimental tile shapes) can only be set to "off"
   const bool exp_switch = !strcmp(name, "gemm_arow") || !strcmp(name, "gemm_wide") || !strcmp(name, "gemm_pipe") ||
-                          !strcmp(name, "conv_im2col");
+                          !strcmp(name, "conv_im2col") || !strcmp(name, "ir_stream");
   if ((exp_switch && value != 0) || (!strcmp(name, "gemm_cfg") && value >= 4)) {
     casync_set_error("option %s=%d needs a library built with CASYNC_EXPERIMENTAL=1", name, value);
     return CASYNC_ERR_STATE;

@@ -40,12 +40,21 @@
 //   slot NB           wave 3: the row tails (hx >= 16 * BT) of the new rows, always
 //                     waves 0, 1: the body tiles of the KEEP carried rows, wave 2: their tails -- only in a FRESH
 //                     step (the first of a run or of a strip), which has nothing carried to start from
+//
+// STATUS (round 3): measured and NOT adopted -- compiled only with CASYNC_EXPERIMENTAL=1, like gemm_experimental.inc.
+// It is bit-identical to the tile kernel (tests/test_ops_gpu.py::test_ir_stream_equals_tile_kernel), issues 19 % fewer
+// MFMAs and 30 % fewer VALU instructions per output pixel, and is 3 % faster on up4's first block alone (0.267 vs
+// 0.277 ms at 32 frames) -- but 1.3 % SLOWER end to end in the two-lane engine (11.25 k vs 11.40 k frames/s, three
+// alternating rounds each, profiles/r3_ab_end_to_end.txt): its 52 KB of LDS and run-long workgroups pack worse with the
+// other lane's kernels than the tile kernel's 6,400 short workgroups.  What the timeline says about it is in DESIGN.md.
 #include <stdlib.h>
 
 #include <type_traits>
 
 #include "common.h"
 #include "ir_common.h"
+
+#ifdef CASYNC_EXPERIMENTAL
 
 namespace {
 
@@ -594,3 +603,15 @@ int launch_ir_stream(const void* lo, int ld_lo, int c_lo, const void* in, int ld
   casync_set_error("ir_stream: no instance for cin=%d cout=%d stride=%d", cin, cout, stride);
   return CASYNC_ERR_ARG;
 }
+
+#else   // product build: the entry points exist, nothing routes to them
+
+bool ir_stream_supported(int, int, int, int, int, bool, int) { return false; }
+const char* ir_stream_kernel_name(int, int, int, bool) { return "ir_stream_kernel (not built)"; }
+int launch_ir_stream(const void*, int, int, const void*, int, const void*, const float*, const float*, const float*, const void*,
+                     const float*, void*, int, int, int, int, int, int, int, int, bool, hipStream_t) {
+  casync_set_error("ir_stream: this library was built without CASYNC_EXPERIMENTAL");
+  return CASYNC_ERR_STATE;
+}
+
+#endif

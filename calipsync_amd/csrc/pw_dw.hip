@@ -29,19 +29,22 @@
 
 namespace {
 
-constexpr int ROWB = 128;   // bytes of one k-tile row (32 floats)
-
-template <int HW, int F, int BN>
+// KF = floats per k-tile row: 32 (128-B rows, gemm.hip's ring) or 16 (64-B rows: half the ring, so that the whole
+// working set of a workgroup stays near the 32 KB of the 64x64 GEMM tiles it shares the CUs with -- a workgroup that
+// fills a CU's LDS shuts the other lane's kernels out, measured -2 % end to end with 74 KB rings)
+template <int HW, int F, int BN, int KF>
 struct FTGeom {
+  static constexpr int ROWB = KF * 4, RPI = 1024 / ROWB;       // row bytes; rows one LDS-DMA instruction fills (8 / 16)
   static constexpr int P = HW * HW, M = F * P, MT = (M + 15) / 16, M_PAD = 16 * MT;
   static constexpr int NT = BN / 16, WPN = 4 / NT;             // n-tiles; waves that share an n-tile
   static constexpr int MTW = (MT + WPN - 1) / WPN;             // m-tiles per wave
-  static constexpr int ROWS = M_PAD + BN, LPT = (ROWS + 31) / 32, STAGE = LPT * 32 * ROWB;
+  static constexpr int ROWS = M_PAD + BN, LPT = (ROWS + 4 * RPI - 1) / (4 * RPI), STAGE = LPT * 4 * RPI * ROWB;
   static constexpr int NQ = BN / 4, PSTEP = 256 / NQ;          // channel quads; pixels a pass of the epilogue covers
   static constexpr size_t etile = (size_t)M_PAD * BN * sizeof(float);
   static constexpr size_t lds = 2 * (size_t)STAGE > etile ? 2 * (size_t)STAGE : etile;
-  static constexpr int occ = (int)(160 * 1024 / lds) >= 2 ? 2 : 1;
+  static constexpr int occ = (int)(160 * 1024 / lds) >= 4 ? 4 : (int)(160 * 1024 / lds);
   static_assert(NT == 2 || NT == 4, "BN = 32 or 64");
+  static_assert(KF == 16 || KF == 32, "64-B or 128-B k-tile rows");
   static_assert(lds <= 160 * 1024, "LDS budget");
 };
 
@@ -52,16 +55,25 @@ __device__ __forceinline__ void ft_dma16(const void* base, unsigned bytes, void*
 #endif
 }
 
-template <int HW, int F, int BN>
-__global__ __launch_bounds__(256, (FTGeom<HW, F, BN>::occ)) void pw_dw_kernel(
+// swizzle key of stage row r: 128-B rows: (r >> 1) & 7 (gemm.hip); 64-B rows: a 4-entry table by (r >> 2) & 3 chosen so
+// that the sixteen rows of a ds_read_b128 service group fall on sixteen different 16-B bank slots
+template <int KF>
+__device__ __forceinline__ int ft_key(int r) {
+  if constexpr (KF == 32) return (r >> 1) & 7;
+  else return (0x1320 >> (4 * ((r >> 2) & 3))) & 3;      // {0, 2, 3, 1}
+}
+
+template <int HW, int F, int BN, int KF>
+__global__ __launch_bounds__(256, (FTGeom<HW, F, BN, KF>::occ)) void pw_dw_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W1, const float* __restrict__ b1,
     const float* __restrict__ wd, const float* __restrict__ bd, float* __restrict__ D, int ldd, int frames, int K, int N,
     int stride, int n_ntiles, int nwg, unsigned a_bytes, unsigned w_bytes) {
-  using G = FTGeom<HW, F, BN>;
+  using G = FTGeom<HW, F, BN, KF>;
+  constexpr int ROWB = G::ROWB, RPI = G::RPI, CPR = ROWB / 16;   // 16-B columns per row
   extern __shared__ __attribute__((aligned(16))) char ring[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15, q = lane >> 4, lrow8 = lane >> 3, lcol = lane & 7;
+  const int l15 = lane & 15, q = lane >> 4, lrow = lane / CPR, lcol = lane % CPR;
 
   // XCD-aware tile order (speed only): workgroups b, b + 8, ... share an XCD; give each XCD a contiguous run of tiles so
   // the channel tiles of one frame group (same A rows) meet in one L2
@@ -74,15 +86,15 @@ __global__ __launch_bounds__(256, (FTGeom<HW, F, BN>::occ)) void pw_dw_kernel(
   }
   const int f0 = ft * F, nf = frames - f0 < F ? frames - f0 : F;   // frames of this tile
   const int m0 = f0 * G::P, m_valid = nf * G::P, n0 = nt * BN;
-  const int nk = K / 32;
+  const int nk = K / KF;
 
   // ---- LDS-DMA: this lane's source offset of each of the wave's LPT instructions (8 rows x 128 B each) ----
   int voff[G::LPT];
 #pragma unroll
   for (int j = 0; j < G::LPT; ++j) {
-    const int r = (j * 4 + wave) * 8 + lrow8;              // row inside the stage: [0, M_PAD) = A, then BN rows of W1
-    const int cs = lcol ^ ((r >> 1) & 7);                  // swizzled source column
-    if ((j * 4 + wave) * 8 < G::M_PAD) {
+    const int r = (j * 4 + wave) * RPI + lrow;             // row inside the stage: [0, M_PAD) = A, then BN rows of W1
+    const int cs = lcol ^ ft_key<KF>(r);                   // swizzled source column
+    if ((j * 4 + wave) * RPI < G::M_PAD) {
       const int row = m0 + (r < m_valid ? r : m_valid - 1);   // pad rows re-read the last pixel; never used
       voff[j] = (int)((long long)row * lda * 4) + cs * 16;
     } else {
@@ -93,16 +105,18 @@ __global__ __launch_bounds__(256, (FTGeom<HW, F, BN>::occ)) void pw_dw_kernel(
   auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < G::LPT; ++j) {
-      char* dst = ring + stage * G::STAGE + (j * 4 + wave) * 8 * ROWB;
-      if ((j * 4 + wave) * 8 < G::M_PAD) ft_dma16(A, a_bytes, dst, voff[j], kt * ROWB);
+      char* dst = ring + stage * G::STAGE + (j * 4 + wave) * RPI * ROWB;
+      if ((j * 4 + wave) * RPI < G::M_PAD) ft_dma16(A, a_bytes, dst, voff[j], kt * ROWB);
       else ft_dma16(W1, w_bytes, dst, voff[j], kt * ROWB);
     }
   };
 
   // ---- MFMA: wave -> channel tile `wn` and the pixel tiles wm, wm + WPN, ... ----
   const int wn = wave % G::NT, wm = wave / G::NT;
-  const int key = (l15 >> 1) & 7;                          // (row >> 1) & 7 of every fragment row 16 t + l15
-  const int frag0 = l15 * ROWB + ((q ^ key) << 4), frag1 = l15 * ROWB + (((4 + q) ^ key) << 4);   // k-groups 0 / 1
+  const int key = ft_key<KF>(l15);                        // key of every fragment row 16 t + l15 (16 t adds nothing)
+  int frag[KF / 16];                                      // this lane's 16 B of each 16-float k-group of a row
+#pragma unroll
+  for (int g = 0; g < KF / 16; ++g) frag[g] = l15 * ROWB + (((4 * g + q) ^ key) << 4);
   f32x4 acc[G::MTW];
 #pragma unroll
   for (int i = 0; i < G::MTW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -113,28 +127,25 @@ __global__ __launch_bounds__(256, (FTGeom<HW, F, BN>::occ)) void pw_dw_kernel(
     __syncthreads();                                   // ... everyone's; and everyone is done reading the other stage
     if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
     const char* st = ring + (kt & 1) * G::STAGE;
+    // all fragments of the k-tile are requested up front, then the MFMAs run back to back: s outer, tile inner, so an
+    // accumulator is reused only every MTW instructions (no dependent-issue stalls)
+    f32x4 fw[KF / 16], fa[KF / 16][G::MTW];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int fo = g ? frag1 : frag0;
-      const f32x4 fw = *reinterpret_cast<const f32x4*>(st + (G::M_PAD + 16 * wn) * ROWB + fo);
-      // two pixel tiles at a time: consecutive MFMAs never wait for their own accumulator
+    for (int g = 0; g < KF / 16; ++g) {
+      fw[g] = *reinterpret_cast<const f32x4*>(st + (G::M_PAD + 16 * wn) * ROWB + frag[g]);
 #pragma unroll
-      for (int i = 0; i < G::MTW; i += 2) {
-        const bool two = i + 1 < G::MTW;
-        const int t0 = wm + G::WPN * i, t1 = wm + G::WPN * (i + 1);
-        if (t0 < G::MT) {
-          const f32x4 fa0 = *reinterpret_cast<const f32x4*>(st + 16 * t0 * ROWB + fo);
-          f32x4 fa1 = fa0;
-          const bool on1 = two && t1 < G::MT;
-          if (on1) fa1 = *reinterpret_cast<const f32x4*>(st + 16 * t1 * ROWB + fo);
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            acc[i] = mfma16(fw[s], fa0[s], acc[i]);
-            if (on1) acc[i + 1] = mfma16(fw[s], fa1[s], acc[i + 1]);
-          }
-        }
+      for (int i = 0; i < G::MTW; ++i) {
+        // a tile index past the end (BN = 32, second wave of the pair) recomputes the last tile and never stores it
+        const int t = wm + G::WPN * i < G::MT ? wm + G::WPN * i : G::MT - 1;
+        fa[g][i] = *reinterpret_cast<const f32x4*>(st + 16 * t * ROWB + frag[g]);
       }
     }
+#pragma unroll
+    for (int g = 0; g < KF / 16; ++g)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < G::MTW; ++i) acc[i] = mfma16(fw[g][s], fa[g][i][s], acc[i]);
   }
   __syncthreads();   // the ring is consumed: it becomes the E tile
 
@@ -186,11 +197,11 @@ __global__ __launch_bounds__(256, (FTGeom<HW, F, BN>::occ)) void pw_dw_kernel(
   }
 }
 
-template <int HW, int F, int BN>
+template <int HW, int F, int BN, int KF>
 int launch_ft(const float* a, int lda, const float* w1, const float* b1, const float* wd, const float* bd, float* d, int ldd,
               int frames, int k, int n, int stride, hipStream_t stream) {
-  using G = FTGeom<HW, F, BN>;
-  auto kern = pw_dw_kernel<HW, F, BN>;
+  using G = FTGeom<HW, F, BN, KF>;
+  auto kern = pw_dw_kernel<HW, F, BN, KF>;
   static unsigned long long attr_once = 0;
   if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)G::lds)) return st;
   const int n_ft = (frames + F - 1) / F, n_nt = n / BN;
@@ -203,25 +214,19 @@ int launch_ft(const float* a, int lda, const float* w1, const float* b1, const f
   return CASYNC_OK;
 }
 
-// channel-tile width: 64 unless that leaves the chip half empty (the launch then has < 256 workgroups)
-inline int ft_bn(int hw, int n, int frames) {
-  if (hw == 20) return 32;
-  const long long ft = hw == 10 ? (frames + 1) / 2 : frames;
-  return n % 64 == 0 && ft * (n / 64) >= 256 ? 64 : 32;
-}
-
 }  // namespace
 
 bool pw_dw_supported(int hw, int cin, int cexp, int stride) {
-  if (cin % 32 || cexp % 64) return false;
+  if (cin % 16 || cexp % 32) return false;
   if (hw == 10 || hw == 16) return stride == 1;
   return hw == 20 && (stride == 1 || stride == 2);
 }
 
 const char* pw_dw_kernel_name(int hw, int cexp, int frames) {
   static thread_local char buf[64];
-  const int bn = hw == 16 ? 64 : ft_bn(hw, cexp, frames);
-  snprintf(buf, sizeof(buf), "pw_dw_kernel<%d, %d, %d>", hw, hw == 10 ? 2 : 1, bn);
+  (void)cexp;
+  (void)frames;
+  snprintf(buf, sizeof(buf), "pw_dw_kernel<%d, %d, 32, 16>", hw, hw == 10 ? 2 : 1);
   return buf;
 }
 
@@ -237,9 +242,8 @@ int launch_pw_dw(const void* a, int lda, const void* w1, const float* b1, const 
   const float* af = static_cast<const float*>(a);
   const float* wf = static_cast<const float*>(w1);
   float* df = static_cast<float*>(d);
-  if (hw == 10)
-    return ft_bn(hw, cexp, frames) == 64 ? launch_ft<10, 2, 64>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, stream)
-                                         : launch_ft<10, 2, 32>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, stream);
-  if (hw == 16) return launch_ft<16, 1, 64>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, stream);
-  return launch_ft<20, 1, 32>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, stream);
+  // 32-channel tiles, 64-B k-tile rows: 31 KB (10x10 frame pairs), 37 KB (16x16), 55 KB (20x20) of LDS per workgroup
+  if (hw == 10) return launch_ft<10, 2, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, stream);
+  if (hw == 16) return launch_ft<16, 1, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, stream);
+  return launch_ft<20, 1, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, stream);
 }

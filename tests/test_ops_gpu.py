@@ -394,6 +394,7 @@ STREAM_CASES = [  # (state_dict prefix, cin, cout, res, ups, h, w, batch): the i
 
 @pytest.mark.parametrize("min_steps", [1, 2, 5, 1000])
 @pytest.mark.parametrize("prefix,cin,cout,res,ups,h,w,b", STREAM_CASES)
+@needs_experimental
 def test_ir_stream_equals_tile_kernel(lib, recipe_sd, prefix, cin, cout, res, ups, h, w, b, min_steps):
     """The row-streaming kernel (ir_stream.hip) against the tile kernel (ir_fused.hip, ir_stream=0) and the oracle:
     same products in the same order, so the two kernels agree BIT FOR BIT -- for every way of cutting the step list
@@ -617,7 +618,7 @@ def test_product_build_refuses_experimental_switches(lib):
     """In a product build the switches of the quarantined kernels can only be 'off', and say why."""
     if _lib.experimental():
         pytest.skip("experimental build: the switches are live")
-    for name, value in (("gemm_arow", 1), ("gemm_wide", 1), ("gemm_pipe", 3), ("conv_im2col", 1), ("gemm_cfg", 6)):
+    for name, value in (("gemm_arow", 1), ("gemm_wide", 1), ("gemm_pipe", 3), ("conv_im2col", 1), ("gemm_cfg", 6), ("ir_stream", 1)):
         with pytest.raises(RuntimeError, match="CASYNC_EXPERIMENTAL"):
             _lib.set_option(name, value)
         _lib.set_option(name, 0 if name != "gemm_cfg" else -1)       # 'off' is always accepted
