@@ -22,7 +22,9 @@ import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kernel_names import short  # noqa: E402
+from calipsync_amd.build import source_hash  # noqa: E402  (sha256 of the kernel sources the counters were collected from)
 
 
 def load(d):
@@ -53,7 +55,7 @@ def main():
         if c.get("SQ_LDS_IDX_ACTIVE"):
             row["lds_bank_conflict"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
         out[k] = row
-    json.dump({"source": f"profiles/{os.path.basename(out_path)}: rocprofv3 --pmc (SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES "
+    json.dump({"source_hash": source_hash(), "source": f"profiles/{os.path.basename(out_path)}: rocprofv3 --pmc (SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES "
                          "GRBM_GUI_ACTIVE | SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS | SQ_LDS_BANK_CONFLICT "
                          "SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS, one group per pass) of `bench.py --replay-only` "
                          "(tools/collect_pmc_busy.sh)",

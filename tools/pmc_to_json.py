@@ -16,7 +16,9 @@ import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kernel_names import short  # noqa: E402
+from calipsync_amd.build import source_hash  # noqa: E402  (sha256 of the kernel sources the counters were collected from)
 
 
 def per_kernel(d, counter):
@@ -39,7 +41,7 @@ for k in sorted(set(fetch) | set(write)):
     wk, _ = write.get(k, (0.0, 0))
     out[k] = {"launches_sampled": n, "fetch_bytes_per_launch": round(2 * fk * 1024), "write_bytes_per_launch": round(wk * 1024),
               "hbm_bytes_per_launch": round((2 * fk + wk) * 1024)}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of bench.py " + (sys.argv[4] if len(sys.argv) > 4 else "B=64 fp32") + ", "
+json.dump({"source_hash": source_hash(), "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of bench.py " + (sys.argv[4] if len(sys.argv) > 4 else "B=64 fp32") + ", "
                      "--replay-only (the timed run's launches, serialised); FETCH_SIZE x2 (gfx950), KB -> bytes",
            "kernels": out}, open(sys.argv[3], "w"), indent=1)
 for k, v in out.items():
