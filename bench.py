@@ -455,9 +455,9 @@ def main():
             "launches_per_step": dom["n"] // reps,
             "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
             "share_of_step": round(dom["ms"] / sum(c["ms"] for c in per.values()), 3),
-            "measured": "HIP events around every launch; the timed run's own launches (same lanes, tiles, grids) "
-                        f"serialised on one stream; profiles/{tag}_kernel_stats_replay.csv is rocprofv3 "
-                        "--kernel-trace --stats of `bench.py --replay-only`",
+            "measured": "HIP events around every launch (minus the calibrated cost of an empty event pair); the timed "
+                        "run's own launches (same lanes, tiles, grids) serialised on one stream; "
+                        f"profiles/{tag}_kernel_stats_replay.csv is rocprofv3 --kernel-trace --stats of `bench.py --replay-only`",
         }
         # HBM-side bytes and MFMA-busy of that kernel from the committed PMC passes (tools/collect_profiles.sh
         # with --replay-only, i.e. these same launches; the counters are per launch, so they do not depend on

@@ -28,6 +28,13 @@ enum { FMASK_NONE = -1, FMASK_F32 = 0, FMASK_U8 = 1 };   // the optional frame m
 constexpr int NPTS = 33;
 constexpr int XY_SHIFT = 16;
 constexpr long long XY_ONE = 1ll << XY_SHIFT;
+// Left end of a fillPoly span: x1 = (xa + FILL_LEFT_DELTA) >> XY_SHIFT.  This file (and oracle/frame_ops_oracle.py)
+// restate FillEdgeCollection of OpenCV 4.5.x drawing.cpp as it was read for round 2: ceil(xa), i.e. XY_ONE - 1.  Later
+// 4.x sources carry a `delta` that is 0 for line types below LINE_AA (fillPoly's default LINE_8), i.e. floor(xa): one
+// pixel more on the left edge wherever the outline has not already drawn it.  cv2 is absent from the build image, so
+// which one the reference's installed version uses is UNPINNED; the rule is this one constant, in both files, and
+// tests/test_frame_ops.py::test_oracle_against_cv2 decides it wherever cv2 exists.
+constexpr long long FILL_LEFT_DELTA = XY_ONE - 1;
 
 // ---- cv::resize INTER_LINEAR tables, one destination index at a time (resize.cpp) ----
 struct Tap { int s0, s1; float f; };
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(64) void frame_polyfill_kernel(const int* __restric
   __syncthreads();
   unsigned char* row = mask + g[G_MASK_OFF] + (size_t)y * w;
   for (int k = 0; k + 1 < n_cross; k += 2) {
-    long long x1 = (xs[k] + XY_ONE - 1) >> XY_SHIFT, x2 = xs[k + 1] >> XY_SHIFT;
+    long long x1 = (xs[k] + FILL_LEFT_DELTA) >> XY_SHIFT, x2 = xs[k + 1] >> XY_SHIFT;
     if (x1 < w && x2 >= 0) {
       if (x1 < 0) x1 = 0;
       if (x2 >= w) x2 = w - 1;

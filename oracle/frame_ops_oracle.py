@@ -30,6 +30,11 @@ import numpy as np
 
 XY_SHIFT = 16
 XY_ONE = 1 << XY_SHIFT
+# Left end of a fillPoly span, x1 = (xa + FILL_LEFT_DELTA) >> XY_SHIFT: ceil(xa) as in FillEdgeCollection of OpenCV 4.5.x
+# (the version restated here).  Later 4.x sources use delta = 0 for line types below LINE_AA, i.e. floor(xa).  UNPINNED
+# (cv2 is absent); the same constant sits in calipsync_amd/csrc/frame_ops.hip, and test_oracle_against_cv2 decides it
+# wherever cv2 is installed.
+FILL_LEFT_DELTA = XY_ONE - 1
 COEF_BITS = 11
 COEF_SCALE = 1 << COEF_BITS
 
@@ -232,7 +237,7 @@ def fill_poly(shape: Tuple[int, int], pts: np.ndarray, color: int = 255) -> np.n
         xs = sorted(e[2] + (y - e[0]) * e[3] for e in edges if e[0] <= y < e[1])
         for k in range(0, len(xs) - 1, 2):
             xa, xb = xs[k], xs[k + 1]
-            x1 = (xa + XY_ONE - 1) >> XY_SHIFT
+            x1 = (xa + FILL_LEFT_DELTA) >> XY_SHIFT
             x2 = xb >> XY_SHIFT
             if x1 < w and x2 >= 0:
                 x1, x2 = max(x1, 0), min(x2, w - 1)
