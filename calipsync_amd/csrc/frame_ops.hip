@@ -29,7 +29,7 @@ constexpr int NPTS = 33;
 constexpr int XY_SHIFT = 16;
 constexpr long long XY_ONE = 1ll << XY_SHIFT;
 // Left end of a fillPoly span: x1 = (xa + FILL_LEFT_DELTA) >> XY_SHIFT.  This file (and oracle/frame_ops_oracle.py)
-// restate FillEdgeCollection of OpenCV 4.5.x drawing.cpp as it was read for round 2: ceil(xa), i.e. XY_ONE - 1.  Later
+// restate FillEdgeCollection of OpenCV 4.x drawing.cpp in its ceil(xa) form (XY_ONE - 1; the form of 3.4 and early 4.x as recalled).  Later
 // 4.x sources carry a `delta` that is 0 for line types below LINE_AA (fillPoly's default LINE_8), i.e. floor(xa): one
 // pixel more on the left edge wherever the outline has not already drawn it.  cv2 is absent from the build image, so
 // which one the reference's installed version uses is UNPINNED; the rule is this one constant, in both files, and

@@ -102,6 +102,11 @@ struct IRGeom {
   static constexpr int NWD = (11 * CC / 4 + 255) / 256;    // Wd, b1, bd are contiguous per chunk in LDS
 };
 
+// Epilogue staging sO [OP][32 columns] of the fp32 kernel: unpadded 128-B rows, 16-B column XOR (pixel & 3).  The
+// stores come from the accumulator layout (eight consecutive pixels, one column: pairs share a bank, free for a 16-B
+// store), the loads walk whole rows (the XOR stays inside each 64-B half, so a service group's rows never meet).
+__device__ __forceinline__ int so_off(int p, int col16) { return p * 32 + ((col16 ^ (p & 3)) << 2); }
+
 // The parked residual tile sX [OP][CIN]: its stores come from the A fragments (eight consecutive lanes = eight
 // consecutive pixels, a CIN x 4 B stride: all on the same banks), its loads walk whole 128-B row slices.  XORing the
 // 16-B column with the low two bits of the pixel leaves pairs of pixels on a bank (free for a 16-B store); for
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
 #pragma unroll
       for (int i = 0; i < G::MT3; ++i) {
         const int p = 16 * (wave * G::MT3 + i) + l15;      // acc3 rows = 4 consecutive output channels
-        *reinterpret_cast<f32x4*>(sO + p * G::LDO + 16 * nn + 4 * q) = lrelu4(acc3[i][n0 + nn] + bias);
+        *reinterpret_cast<f32x4*>(sO + so_off(p, 4 * nn + q)) = lrelu4(acc3[i][n0 + nn] + bias);
       }
     }
     __syncthreads();
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
       const int py = p / TW, px = p - py * TW;
       const int oy = oy0 + py, ox = ox0 + px;
       if (oy < Ho && ox < Wo) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(sO + p * G::LDO + c4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(sO + so_off(p, c4 >> 2));
         const int c = 16 * n0 + c4;
         if (res) {   // stride 1, CIN == COUT: + the block input pixel
           if constexpr (G::RESC && sizeof(T) == 4) v += *reinterpret_cast<const f32x4*>(sX + p * CIN + (((c >> 2) ^ xkey<CIN>(p)) << 2));

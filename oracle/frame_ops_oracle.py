@@ -30,7 +30,7 @@ import numpy as np
 
 XY_SHIFT = 16
 XY_ONE = 1 << XY_SHIFT
-# Left end of a fillPoly span, x1 = (xa + FILL_LEFT_DELTA) >> XY_SHIFT: ceil(xa) as in FillEdgeCollection of OpenCV 4.5.x
+# Left end of a fillPoly span, x1 = (xa + FILL_LEFT_DELTA) >> XY_SHIFT: ceil(xa) as in FillEdgeCollection of OpenCV 3.4 / early 4.x (as recalled)
 # (the version restated here).  Later 4.x sources use delta = 0 for line types below LINE_AA, i.e. floor(xa).  UNPINNED
 # (cv2 is absent); the same constant sits in calipsync_amd/csrc/frame_ops.hip, and test_oracle_against_cv2 decides it
 # wherever cv2 is installed.
