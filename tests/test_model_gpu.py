@@ -225,8 +225,9 @@ def test_bf16_frames_independent(net_bf16):
 def test_full_size_batch_properties(recipe_sd, precision):
     """BASELINE configs[2]/[3] per-GPU size (512 frames): no oracle run at this size; instead the
     size-independent properties -- every frame equals its own single-frame forward (frames
-    independent, lanes / tiling batch-invariant: bit for bit with plain GEMM tiles, to rounding
-    with the stream-K k-split), duplicates agree, outputs in (0,1)."""
+    independent, lanes / tiling batch-invariant: bit for bit with plain GEMM tiles and one kernel choice for all
+    batch sizes, to rounding with the stream-K k-split / the batch-dependent kernel choice), duplicates agree,
+    outputs in (0,1)."""
     m = Model(6, "hubert", precision=precision).to("cuda:0")
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe_sd.items()})
     x16, a16 = recipe.make_inputs(16)
@@ -241,7 +242,10 @@ def test_full_size_batch_properties(recipe_sd, precision):
     for i in (0, 7, 15):
         single = m(x[i:i + 1].contiguous(), a[i:i + 1].contiguous())
         assert (single[0] - out[i]).abs().max() < tol, i
+    # bit for bit: plain GEMM tiles (the stream-K k-split depends on the row count) and the same kernels at every batch
+    # size (the fused expand+depthwise kernel is only used from 16 frames per launch up)
     m.set_option("gemm_streamk", 0)
+    m.set_option("fuse_dw", 0)
     out = m(x, a)
     assert torch.equal(out[:16], out[256:272]) and torch.equal(out[5], out[16 * 31 + 5])
     for i in (0, 7, 15):
