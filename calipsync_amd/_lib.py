@@ -56,7 +56,9 @@ _PROTOS = {
     "casync_op_dw3x3": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_void_p]),
     "casync_op_pw_dw": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                  C.c_int, C.c_int, C.c_void_p]),
+                                  C.c_int, C.c_int, c_f32p, C.c_int, C.c_void_p]),
+    "casync_op_pw_gemm_ups": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        c_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "casync_op_ir_fused": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                      c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_void_p]),

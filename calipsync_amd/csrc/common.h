@@ -86,6 +86,8 @@ struct CasyncOptions {
   int fuse_up = 1;           // CASYNC_FUSE_UP: bilinear upsample folded into up3/up4
   int fuse_min_hw = 32;      // CASYNC_FUSE_MIN_HW: lowest resolution the fused kernel is used at
   int fuse_q = 1;            // CASYNC_FUSE_Q: query projection as 64 extra columns of the p_1 GEMM
+  int ups_commute = 1;       // CASYNC_UPS_COMMUTE: Up blocks run the upsampled half of their expand conv at the low resolution
+                             //   (upsample and 1x1 conv commute), fp32; 0 = upsample first, as the reference writes it
   int fuse_dw = 1;           // CASYNC_FUSE_DW: expand GEMM + depthwise 3x3 in one kernel below 32x32 (pw_dw.hip), fp32
   int ir_stream = 0;         // CASYNC_IR_STREAM: row-streaming fused block (ir_stream.hip; experimental builds only): 1 = where
                              //   it beats the tile kernel in isolation, 2 = every shape it has an instance for
@@ -169,6 +171,11 @@ struct GemmEpilogue {
   const float* aff_s = nullptr;      // [N] v = lrelu(v*aff_s + aff_t) on the OUTPUT (aff_on_acc=0)
   const float* aff_t = nullptr;      //     or on the running accumulator (aff_on_acc=1)
   int aff_on_acc = 0;
+  // + bilinear x2 upsample (align_corners=True) of a LOW-resolution tensor, added before the activation: the rows of C
+  // are the pixels (b, y, x) of ups_h x ups_w frames, ups_src is [B * ups_h/2 * ups_w/2, ups_ld].  This is how an Up
+  // block's expand conv takes its upsampled half: W1 . cat(up(lo), skip) = up(W1a . lo) + W1b . skip (module/unet.py:90-96)
+  const void* ups_src = nullptr;     // (T)
+  int ups_ld = 0, ups_h = 0, ups_w = 0;
   const void* acc_in = nullptr;      // (T) running sum: acc_out = acc_in + v
   void* acc_out = nullptr;           // (T)
   int ld_acc = 0;
@@ -233,8 +240,10 @@ int launch_ir_fused(const void* in, int ld_in, const void* w1, const float* b1, 
 // 20x20 frames; a [frames*hw*hw, lda], w1 [cexp][cin], wd [9][cexp], d [frames*ho*ho, ldd]
 bool pw_dw_supported(int hw, int cin, int cexp, int stride);
 const char* pw_dw_kernel_name(int hw, int cexp, int frames);
+// ups (optional): low-resolution addend [frames*(hw/2)^2, ld_ups] whose bilinear x2 upsample is added before the first
+// activation (an Up block's upsampled half, see GemmEpilogue::ups_src)
 int launch_pw_dw(const void* a, int lda, const void* w1, const float* b1, const float* wd, const float* bd, void* d, int ldd,
-                 int frames, int hw, int stride, int cin, int cexp, hipStream_t stream);
+                 int frames, int hw, int stride, int cin, int cexp, hipStream_t stream, const void* ups = nullptr, int ld_ups = 0);
 int launch_im2col3x3(const void* in, void* out, int batch, int h, int wdt, int c, int stride,
                      int pad, hipStream_t stream, int dtype = DT_F32);
 int launch_upsample2x(const void* in, void* out, int ldc, int batch, int h, int wdt, int c,

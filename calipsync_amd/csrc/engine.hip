@@ -133,6 +133,12 @@ const Layout& layout() {
     for (auto& b : kFuse) l.add_ir(b);
     for (auto& st : kUp)
       for (auto& b : st) l.add_ir(b);
+    // Up blocks: the two K-halves of the first block's expand matrix as matrices of their own -- [cexp][cin/2] for the
+    // upsampled input (applied at the low resolution: upsample and 1x1 conv commute) and for the skip
+    for (auto& st : kUp) {
+      l.add(std::string(st[0].prefix) + ".pw1a.w", (int64_t)st[0].cexp() * (st[0].cin / 2));
+      l.add(std::string(st[0].prefix) + ".pw1b.w", (int64_t)st[0].cexp() * (st[0].cin / 2));
+    }
     l.add("outc.w", 96);  // [3][32], outc_bn folded in
     l.add("outc.b", 3);
     return l;
@@ -184,7 +190,7 @@ struct Arena {
   };
   int esz = 4;
   enum Id {
-    CAT4, CAT3, CAT2, CAT1, CATA, E1, E2, T0, U4, F, FM, U1, U2, U3,
+    CAT4, CAT3, CAT2, CAT1, CATA, E1, E2, T0, U4, F, FM, U1, U2, U3, UG,
     A0, AC1, AC2, IM, AC3, AC4, AC5, AC6, AE1, AE2,
     H, TX, OX0, OX1, OX2, OX3, KX, KXF, P1Q, AO, Q, KV, COUNT
   };
@@ -193,7 +199,8 @@ struct Arena {
       {"cat1", 20 * 20 * 512, 0},   {"catA", 100 * 1024, 0},     {"E1", 160 * 160 * 128, 0},
       {"E2", 160 * 160 * 128, 0},   {"T0", 160 * 160 * 32, 0},   {"U4", 160 * 160 * 32, 0},
       {"F", 100 * 256, 0},          {"FM", 100 * 512, 0},        {"U1", 400 * 128, 0},
-      {"U2", 1600 * 64, 0},         {"U3", 6400 * 32, 0},        {"A0", 1024 * 32, 0},
+      {"U2", 1600 * 64, 0},         {"U3", 6400 * 32, 0},        {"UG", 6400 * 128, 0},   // W1a . lo of an Up block, low res
+      {"A0", 1024 * 32, 0},
       {"AC1", 1024 * 64, 0},        {"AC2", 1024 * 128, 0},      {"IM", 256 * 1152, 0},
       {"AC3", 256 * 256, 0},        {"AC4", 256 * 256, 0},       {"AC5", 100 * 512, 0},
       {"AC6", 100 * 512, 0},        {"AE1", 131072, 0},          {"AE2", 131072, 0},
@@ -377,7 +384,7 @@ struct Plan {
             int ldc, long long m, int n, int k, GemmEpilogue epi, const std::string& bname = "",
             double alg_flops = 0) {
     const void* w = e.WG(wname);
-    epi.bias = e.W(bname.empty() ? wname.substr(0, wname.size() - 1) + "b" : bname);
+    epi.bias = bname == "-" ? nullptr : e.W(bname.empty() ? wname.substr(0, wname.size() - 1) + "b" : bname);   // "-": none
     const double es = dtype_size(dt());
     double bytes = es * ((double)m * k + (double)m * n + (double)n * k);
     if (epi.pre_res) bytes += es * m * n;
@@ -425,11 +432,16 @@ struct Plan {
   }
 
   // One inverted-residual block.  in: [B*hw_in^2, cin] (ld_in); out: [B*hw_out^2, cout] (ld_out).
+  // `ups` (an Up block's first inverted residual with ups_commute): `in` is only the SKIP half of the concatenated
+  // input (k_in = cin / 2 channels, expand matrix pw1b), and ups = W1a . lo at the low resolution, whose bilinear x2
+  // upsample the expand conv adds before its activation.
   void ir(const IR& b, Ptr in, int ld_in, Ptr out, int ld_out, Ptr e1, Ptr e2,
-          const GemmEpilogue* extra = nullptr) {
+          const GemmEpilogue* extra = nullptr, Ptr ups = Ptr{}) {
     const std::string p = b.prefix;
     const long long m_in = (long long)B * b.hw_in * b.hw_in, m_out = (long long)B * b.hw_out() * b.hw_out();
-    if (!extra && ir_is_fused(o, b)) {
+    const int k_in = ups.p ? b.cin / 2 : b.cin;
+    const std::string w1name = p + (ups.p ? ".pw1b.w" : ".pw1.w");
+    if (!extra && !ups.p && ir_is_fused(o, b)) {
       const double flops = 2.0 * (m_in * (double)b.cin * b.cexp() + 9.0 * m_out * b.cexp() +
                                   (double)m_out * b.cexp() * b.cout);
       r.run((p + ".fused").c_str(), ir_fused_kernel_name(b.cin, b.cout, b.stride, dt(), false, b.hw_in, b.hw_in), flops,
@@ -441,18 +453,25 @@ struct Plan {
       return;
     }
     // (from 16 frames per launch: below that its whole-frame tiles are too few to fill the chip -- B=1 0.92 vs 0.82 ms)
-    if (dt() == DT_F32 && o.fuse_dw && B >= 16 && pw_dw_supported(b.hw_in, b.cin, b.cexp(), b.stride)) {
+    if (dt() == DT_F32 && o.fuse_dw && B >= 16 && pw_dw_supported(b.hw_in, k_in, b.cexp(), b.stride)) {
       // expand GEMM whose output tile is whole frames: the depthwise conv runs on the tile in LDS, E never exists
+      // (flops: the reference's own formulation, whatever half of it runs at the low resolution)
       r.run((p + ".pw1dw").c_str(), pw_dw_kernel_name(b.hw_in, b.cexp(), B),
-            2.0 * (m_in * (double)b.cin * b.cexp() + 9.0 * m_out * b.cexp()),
-            4.0 * (m_in * (double)b.cin + (double)b.cexp() * b.cin + (double)m_out * b.cexp()), [&] {
-        return launch_pw_dw(in, ld_in, e.W(p + ".pw1.w"), e.W(p + ".pw1.b"), e.W(p + ".dw.w"), e.W(p + ".dw.b"), e2,
-                            b.cexp(), B, b.hw_in, b.stride, b.cin, b.cexp(), r.s);
+            2.0 * (m_in * (double)(ups.p ? b.cin * 5 / 8.0 : b.cin) * b.cexp() + 9.0 * m_out * b.cexp()),
+            4.0 * (m_in * (double)k_in + (double)b.cexp() * k_in + (double)m_out * b.cexp()), [&] {
+        return launch_pw_dw(in, ld_in, e.W(w1name), e.W(p + ".pw1.b"), e.W(p + ".dw.w"), e.W(p + ".dw.b"), e2,
+                            b.cexp(), B, b.hw_in, b.stride, k_in, b.cexp(), r.s, ups.p, b.cexp());
       });
     } else {
       GemmEpilogue ep1;
       ep1.act = 1;
-      gemm(p + ".pw1", in, ld_in, p + ".pw1.w", e1, b.cexp(), m_in, b.cexp(), b.cin, ep1);
+      if (ups.p) {
+        ep1.ups_src = ups;
+        ep1.ups_ld = b.cexp();
+        ep1.ups_h = ep1.ups_w = b.hw_in;
+      }
+      gemm(p + ".pw1", in, ld_in, w1name, e1, b.cexp(), m_in, b.cexp(), k_in, ep1, p + ".pw1.b",
+           ups.p ? 2.0 * m_in * (b.cin * 5 / 8.0) * b.cexp() : 0);
       r.run((p + ".dw").c_str(), dw3x3_kernel_name(b.hw_in, b.hw_in, b.cexp(), b.stride, dt()),
             2.0 * 9 * m_out * b.cexp(), dtype_size(dt()) * (double)(m_in + m_out) * b.cexp(), [&] {
         return launch_dw3x3(e1, e.W(p + ".dw.w"), e.W(p + ".dw.b"), e2, B, b.hw_in, b.hw_in, b.cexp(),
@@ -608,7 +627,15 @@ struct Plan {
     for (int i = 0; i < 4; ++i) {
       const int cc = 2 * c;  // concat width
       const IR& b0 = kUp[i][0];
-      if (up_is_fused(o, b0)) {
+      const bool commute = o.ups_commute && dt() == DT_F32 && !up_is_fused(o, b0);
+      if (commute) {
+        // upsample and 1x1 conv commute: the upsampled half of the expand conv runs on the LOW-resolution tensor
+        // (a quarter of the pixels: 37.5 % of this GEMM's multiply-adds never happen), the consumer adds its bilinear
+        // x2 upsample before the activation.  Flops are booked where the reference has them (the consumer).
+        gemm(std::string(b0.prefix) + ".pw1a", lo, c, std::string(b0.prefix) + ".pw1a.w", ar[A::UG], b0.cexp(),
+             (long long)B * hw * hw, b0.cexp(), c, GemmEpilogue(), "-", 2.0 * B * hw * hw * (double)c * b0.cexp());
+        ir(b0, cat[i] + c, cc, T0, b0.cout, E1, E2, nullptr, ar[A::UG]);
+      } else if (up_is_fused(o, b0)) {
         // bilinear x2 folded into the fused block's input load: up(x) is never materialised
         const std::string p = b0.prefix;
         const double m = (double)B * 4 * hw * hw;
@@ -1086,9 +1113,20 @@ int casync_op_dw3x3(const void* in, const float* w, const float* bias, void* out
   return launch_dw3x3(in, w, bias, out, batch, h, wdt, c, stride, (hipStream_t)stream, g_op_dtype);
 }
 int casync_op_pw_dw(const void* a, int lda, const void* w1, const float* b1, const float* wd, const float* bd, void* d, int ldd,
-                    int frames, int hw, int stride, int cin, int cexp, casync_stream stream) {
+                    int frames, int hw, int stride, int cin, int cexp, const void* ups, int ld_ups, casync_stream stream) {
   CASYNC_REQUIRE(g_op_dtype == DT_F32, "pw_dw: fp32 only");
-  return launch_pw_dw(a, lda, w1, b1, wd, bd, d, ldd, frames, hw, stride, cin, cexp, (hipStream_t)stream);
+  return launch_pw_dw(a, lda, w1, b1, wd, bd, d, ldd, frames, hw, stride, cin, cexp, (hipStream_t)stream, ups, ld_ups);
+}
+int casync_op_pw_gemm_ups(const void* a, int lda, const void* w, const float* bias, void* c, int ldc, int m, int n, int k, int act,
+                          const void* ups, int ld_ups, int h, int w_, casync_stream stream) {
+  GemmEpilogue e;
+  e.bias = bias;
+  e.act = act;
+  e.ups_src = ups;
+  e.ups_ld = ld_ups;
+  e.ups_h = h;
+  e.ups_w = w_;
+  return launch_pw_gemm(a, lda, w, c, ldc, m, n, k, e, (hipStream_t)stream, g_op_dtype);
 }
 int casync_op_ir_fused(const void* in, int ld_in, const void* w1, const float* b1, const float* wd,
                        const float* bd, const void* w2, const float* b2, void* out, int ld_out,

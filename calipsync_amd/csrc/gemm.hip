@@ -108,6 +108,22 @@ __device__ __forceinline__ void epilogue_rows_cols(const float* Cs, int m0, int 
 #pragma unroll
       for (int q = 0; q < 4; ++q) v.v[e + q] = c[q] + k.bias[e + q];
     }
+    if (epi.ups_src) {
+      const int hw = epi.ups_h * epi.ups_w, Hl = epi.ups_h >> 1, Wl = epi.ups_w >> 1;
+      const int b = m / hw, rem = m - b * hw, y = rem / epi.ups_w, x = rem - y * epi.ups_w;
+      const UpsTap ty = ups_tap((float)(Hl - 1) / (float)(epi.ups_h - 1), y, Hl);
+      const UpsTap tx = ups_tap((float)(Wl - 1) / (float)(epi.ups_w - 1), x, Wl);
+      const T* g = static_cast<const T*>(epi.ups_src) + (size_t)b * Hl * Wl * epi.ups_ld + n;
+#pragma unroll
+      for (int e = 0; e < CPT; e += 4) {
+        const f32x4 r = ups_lerp(ty, tx, ld4(g + ((size_t)ty.i0 * Wl + tx.i0) * epi.ups_ld + e),
+                                 ld4(g + ((size_t)ty.i0 * Wl + tx.i1) * epi.ups_ld + e),
+                                 ld4(g + ((size_t)ty.i1 * Wl + tx.i0) * epi.ups_ld + e),
+                                 ld4(g + ((size_t)ty.i1 * Wl + tx.i1) * epi.ups_ld + e));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v.v[e + q] += r[q];
+      }
+    }
     if (epi.pre_res) {
       const V16<T> r = ld16(static_cast<const T*>(epi.pre_res) + (size_t)m * epi.ld_pre + n);
 #pragma unroll
@@ -1019,6 +1035,9 @@ int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int 
   CASYNC_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)c % 16) == 0,
                  "pw_gemm: A/W/C must be 16-B aligned");
   CASYNC_REQUIRE(!epi.acc_out || epi.acc_in, "pw_gemm: acc_out without acc_in");
+  CASYNC_REQUIRE(!epi.ups_src || (epi.ups_h > 2 && epi.ups_w > 2 && epi.ups_h % 2 == 0 && epi.ups_w % 2 == 0 && epi.ups_ld >= n &&
+                                  epi.ups_ld % e16 == 0 && (uintptr_t)epi.ups_src % 16 == 0 && m % (epi.ups_h * epi.ups_w) == 0),
+                 "pw_gemm: bad upsampled addend (%dx%d, ld %d)", epi.ups_h, epi.ups_w, epi.ups_ld);
   CASYNC_REQUIRE((!epi.pre_res || epi.ld_pre % e16 == 0) && (!epi.post_res || epi.ld_post % e16 == 0) &&
                      (!epi.acc_out || epi.ld_acc % e16 == 0),
                  "pw_gemm: residual leading dimensions must be multiples of %d", e16);

@@ -67,7 +67,7 @@ template <int HW, int F, int BN, int KF>
 __global__ __launch_bounds__(256, (FTGeom<HW, F, BN, KF>::occ)) void pw_dw_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W1, const float* __restrict__ b1,
     const float* __restrict__ wd, const float* __restrict__ bd, float* __restrict__ D, int ldd, int frames, int K, int N,
-    int stride, int n_ntiles, int nwg, unsigned a_bytes, unsigned w_bytes) {
+    int stride, int n_ntiles, int nwg, unsigned a_bytes, unsigned w_bytes, const float* __restrict__ ups, int ld_ups) {
   using G = FTGeom<HW, F, BN, KF>;
   constexpr int ROWB = G::ROWB, RPI = G::RPI, CPR = ROWB / 16;   // 16-B columns per row
   extern __shared__ __attribute__((aligned(16))) char ring[];
@@ -158,7 +158,20 @@ __global__ __launch_bounds__(256, (FTGeom<HW, F, BN, KF>::occ)) void pw_dw_kerne
       const int t = wm + G::WPN * i;
       if (t < G::MT) {
         const int px = 16 * t + l15;
-        *reinterpret_cast<f32x4*>(sE + px * BN + (((4 * wn + q) ^ (px & 7)) << 2)) = lrelu4(acc[i] + bias);
+        f32x4 v = acc[i] + bias;
+        if (ups && px < m_valid) {
+          // + the bilinear x2 upsample of the low-resolution half of an Up block's expand conv (it commutes with the
+          // 1x1 conv: common.h GemmEpilogue::ups_src), HW/2 x HW/2 frames of ld_ups channels
+          constexpr int HL = HW / 2;
+          const int f = px / G::P, rem = px - f * G::P, y = rem / HW, x = rem - y * HW;
+          const UpsTap ty = ups_tap((float)(HL - 1) / (float)(HW - 1), y, HL), tx = ups_tap((float)(HL - 1) / (float)(HW - 1), x, HL);
+          const float* g = ups + (size_t)(f0 + f) * HL * HL * ld_ups + n0 + 16 * wn + 4 * q;
+          v += ups_lerp(ty, tx, *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i0 * HL + tx.i0) * ld_ups),
+                        *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i0 * HL + tx.i1) * ld_ups),
+                        *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i1 * HL + tx.i0) * ld_ups),
+                        *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i1 * HL + tx.i1) * ld_ups));
+        }
+        *reinterpret_cast<f32x4*>(sE + px * BN + (((4 * wn + q) ^ (px & 7)) << 2)) = lrelu4(v);
       }
     }
   }
@@ -199,7 +212,7 @@ __global__ __launch_bounds__(256, (FTGeom<HW, F, BN, KF>::occ)) void pw_dw_kerne
 
 template <int HW, int F, int BN, int KF>
 int launch_ft(const float* a, int lda, const float* w1, const float* b1, const float* wd, const float* bd, float* d, int ldd,
-              int frames, int k, int n, int stride, hipStream_t stream) {
+              int frames, int k, int n, int stride, const float* ups, int ld_ups, hipStream_t stream) {
   using G = FTGeom<HW, F, BN, KF>;
   auto kern = pw_dw_kernel<HW, F, BN, KF>;
   static unsigned long long attr_once = 0;
@@ -209,7 +222,7 @@ int launch_ft(const float* a, int lda, const float* w1, const float* b1, const f
   const unsigned long long ab = ((unsigned long long)((long long)frames * G::P - 1) * lda + k) * 4, wb = (unsigned long long)n * k * 4;
   CASYNC_REQUIRE(nwg < (1ll << 31) && ab < (1ull << 31) && wb < (1ull << 31), "pw_dw: operand larger than 2 GiB");
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), G::lds, stream, a, lda, w1, b1, wd, bd, d, ldd, frames, k, n, stride,
-                     n_nt, (int)nwg, (unsigned)ab, (unsigned)wb);
+                     n_nt, (int)nwg, (unsigned)ab, (unsigned)wb, ups, ld_ups);
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }
@@ -231,11 +244,13 @@ const char* pw_dw_kernel_name(int hw, int cexp, int frames) {
 }
 
 int launch_pw_dw(const void* a, int lda, const void* w1, const float* b1, const float* wd, const float* bd, void* d, int ldd,
-                 int frames, int hw, int stride, int cin, int cexp, hipStream_t stream) {
+                 int frames, int hw, int stride, int cin, int cexp, hipStream_t stream, const void* ups, int ld_ups) {
   CASYNC_REQUIRE(a && w1 && b1 && wd && bd && d && frames > 0, "pw_dw: bad args");
   CASYNC_REQUIRE(pw_dw_supported(hw, cin, cexp, stride), "pw_dw: no instance for %dx%d cin=%d cexp=%d stride=%d", hw, hw, cin, cexp,
                  stride);
   CASYNC_REQUIRE(lda >= cin && lda % 4 == 0 && ldd >= cexp && ldd % 4 == 0, "pw_dw: bad leading dimensions");
+  CASYNC_REQUIRE(!ups || (ld_ups >= cexp && ld_ups % 4 == 0 && (uintptr_t)ups % 16 == 0 && hw % 2 == 0), "pw_dw: bad upsampled addend");
+  const float* uf = static_cast<const float*>(ups);
   CASYNC_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)w1 % 16) == 0 && ((uintptr_t)d % 16) == 0 && ((uintptr_t)b1 % 16) == 0 &&
                      ((uintptr_t)wd % 16) == 0 && ((uintptr_t)bd % 16) == 0,
                  "pw_dw: pointers must be 16-B aligned");
@@ -243,7 +258,7 @@ int launch_pw_dw(const void* a, int lda, const void* w1, const float* b1, const 
   const float* wf = static_cast<const float*>(w1);
   float* df = static_cast<float*>(d);
   // 32-channel tiles, 64-B k-tile rows: 31 KB (10x10 frame pairs), 37 KB (16x16), 55 KB (20x20) of LDS per workgroup
-  if (hw == 10) return launch_ft<10, 2, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, stream);
-  if (hw == 16) return launch_ft<16, 1, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, stream);
-  return launch_ft<20, 1, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, stream);
+  if (hw == 10) return launch_ft<10, 2, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, uf, ld_ups, stream);
+  if (hw == 16) return launch_ft<16, 1, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, uf, ld_ups, stream);
+  return launch_ft<20, 1, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, uf, ld_ups, stream);
 }

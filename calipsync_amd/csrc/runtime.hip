@@ -33,6 +33,7 @@ const OptField kFields[] = {
     {"fuse_up", &CasyncOptions::fuse_up},
     {"fuse_min_hw", &CasyncOptions::fuse_min_hw},
     {"fuse_q", &CasyncOptions::fuse_q},
+    {"ups_commute", &CasyncOptions::ups_commute},
     {"fuse_dw", &CasyncOptions::fuse_dw},
     {"ir_stream", &CasyncOptions::ir_stream},
     {"ir_stream_min", &CasyncOptions::ir_stream_min},

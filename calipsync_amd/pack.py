@@ -71,6 +71,15 @@ def fold(sd: Mapping) -> Dict[str, np.ndarray]:
                 tmp[f"{b.prefix}.pw2.w"].reshape(-1), tmp[f"{b.prefix}.pw2.b"]])
         else:
             _fold_ir(sd, b, out)
+    # Up blocks (module/unet.py:90-96): x = cat([up(lo), skip]).  The bilinear upsample is linear per channel and the
+    # 1x1 conv linear per pixel, so they commute: W1 . cat(up(lo), skip) = up(W1a . lo) + W1b . skip.  The engine runs
+    # the W1a half at the LOW resolution (a quarter of the pixels) -- the two halves are packed as matrices of their own.
+    for st in arch.decoder():
+        b = st[0]
+        w1 = out[f"{b.prefix}.pw1.w"]
+        c_lo = b.cin // 2
+        out[f"{b.prefix}.pw1a.w"] = np.ascontiguousarray(w1[:, :c_lo])
+        out[f"{b.prefix}.pw1b.w"] = np.ascontiguousarray(w1[:, c_lo:])
     _fold_dense3x3(sd, "audio_model.conv3", "audio_model.bn3", out)
     _fold_dense3x3(sd, "audio_model.conv5", "audio_model.bn5", out)
     s7, t7 = _bn_affine(sd, "audio_model.bn7")

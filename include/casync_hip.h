@@ -173,7 +173,15 @@ int casync_op_dw3x3(const void* in, const float* w, const float* bias, void* out
  * runs on it in LDS.  a [frames*hw*hw, lda], w1 [cexp][cin], b1 [cexp], wd [9][cexp] tap-major, bd [cexp],
  * d [frames*ho*ho, ldd].  hw in {10, 16, 20} (stride 2 only at 20), cin % 32 == 0, cexp % 64 == 0.           */
 int casync_op_pw_dw(const void* a, int lda, const void* w1, const float* b1, const float* wd, const float* bd,
-                    void* d, int ldd, int frames, int hw, int stride, int cin, int cexp, casync_stream stream);
+                    void* d, int ldd, int frames, int hw, int stride, int cin, int cexp, const void* ups, int ld_ups,
+                    casync_stream stream);
+/* 1x1 conv + bias + [bilinear x2 upsample (align_corners=True) of a low-resolution tensor] + LeakyReLU:
+ * c[m, :] = act(a[m, :] . w^T + bias + up2x(ups)[m, :]), rows m = pixels (b, y, x) of h x w frames, ups
+ * [B*(h/2)*(w/2), ld_ups].  An Up block's expand conv (module/unet.py:90-96 + 17-20) with the upsample commuted behind
+ * the conv: W1 . cat(up(lo), skip) = up(W1a . lo) + W1b . skip; `ups` = W1a . lo, a = skip, w = W1b.  casync_op_pw_dw
+ * takes the same optional addend (ups may be NULL there).                                                   */
+int casync_op_pw_gemm_ups(const void* a, int lda, const void* w, const float* bias, void* c, int ldc, int m, int n,
+                          int k, int act, const void* ups, int ld_ups, int h, int w_, casync_stream stream);
 /* Whole inverted-residual block in one kernel (expanded tensor stays in LDS); the
  * high-resolution stages use it.  Replaces InvertedResidual.forward
  * (module/unet.py:16-40) with BN folded: w1 [2cin][cin], wd [9][2cin], w2 [cout][2cin]

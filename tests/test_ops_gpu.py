@@ -378,10 +378,45 @@ def test_pw_dw_fused(lib, hw, stride, cin, cexp, frames):
     wdp = wd.reshape(cexp, 9).T.contiguous().to(dev())          # tap-major [9][C]
     w1d, b1d, bdd = w1.to(dev()), b1.to(dev()), bd.to(dev())
     ok(lib.casync_op_pw_dw(xin.data_ptr() + 32 * 4, lda, ptr(w1d), ptr(b1d), ptr(wdp), ptr(bdd), out.data_ptr() + 16 * 4, ldd,
-                           frames, hw, stride, cin, cexp, stream()))
+                           frames, hw, stride, cin, cexp, 0, 0, stream()))
     o = out.cpu()
     assert (o[..., :16] == -7).all()
     assert rel_err(o[..., 16:].permute(0, 3, 1, 2), ref) < 3e-6
+
+
+@pytest.mark.parametrize("hw,c_lo,cexp,frames,fused", [(20, 256, 1024, 3, True), (20, 256, 1024, 17, True), (40, 128, 512, 2, False),
+                                                   (20, 64, 256, 2, False), (16, 32, 128, 1, True)])
+def test_up_block_expand_with_commuted_upsample(lib, hw, c_lo, cexp, frames, fused):
+    """An Up block's expand conv with the bilinear upsample commuted behind it (module/unet.py:90-96 + 17-20):
+    lrelu(W1 . cat(up(lo), skip) + b) == lrelu(up(W1a . lo) + W1b . skip + b).  `G = W1a . lo` runs at the low resolution
+    through the plain GEMM; the consumer is the GEMM epilogue (casync_op_pw_gemm_ups) or, with the depthwise conv behind
+    it, casync_op_pw_dw.  Reference: plain PyTorch in float64, the reference's own order of operations."""
+    g = torch.Generator().manual_seed(hw + c_lo + frames)
+    lo = torch.randn(frames, c_lo, hw // 2, hw // 2, generator=g)
+    skip = torch.randn(frames, c_lo, hw, hw, generator=g)
+    w1 = torch.randn(cexp, 2 * c_lo, generator=g) / (2 * c_lo) ** 0.5
+    b1 = torch.randn(cexp, generator=g) * 0.3
+    x = torch.cat([F.interpolate(lo.double(), scale_factor=2, mode="bilinear", align_corners=True), skip.double()], 1)
+    e = F.leaky_relu(F.conv2d(x, w1.double()[:, :, None, None], b1.double()), 0.01)
+    lod, skd = nhwc(lo), nhwc(skip)
+    w1a, w1b, b1d = w1[:, :c_lo].contiguous().to(dev()), w1[:, c_lo:].contiguous().to(dev()), b1.to(dev())
+    G = torch.empty(frames * (hw // 2) ** 2, cexp, device=dev())
+    ok(lib.casync_op_pw_gemm(ptr(lod), c_lo, ptr(w1a), 0, ptr(G), cexp, G.shape[0], cexp, c_lo, 0, 0, 0, 0, 0, 0, 0, 0, stream()))
+    if not fused:
+        out = torch.empty(frames * hw * hw, cexp, device=dev())
+        ok(lib.casync_op_pw_gemm_ups(ptr(skd), c_lo, ptr(w1b), ptr(b1d), ptr(out), cexp, out.shape[0], cexp, c_lo, 1, ptr(G), cexp,
+                                     hw, hw, stream()))
+        got = out.view(frames, hw, hw, cexp).permute(0, 3, 1, 2).cpu()
+        assert rel_err(got, e.float()) < 3e-6
+        return
+    wd = torch.randn(cexp, 1, 3, 3, generator=g) / 3
+    bd = torch.randn(cexp, generator=g) * 0.3
+    ref = F.leaky_relu(F.conv2d(e, wd.double(), bd.double(), 1, 1, 1, cexp), 0.01).float()
+    out = torch.empty(frames, hw, hw, cexp, device=dev())
+    wdp, bdd = wd.reshape(cexp, 9).T.contiguous().to(dev()), bd.to(dev())
+    ok(lib.casync_op_pw_dw(ptr(skd), c_lo, ptr(w1b), ptr(b1d), ptr(wdp), ptr(bdd), ptr(out), cexp, frames, hw, 1, c_lo, cexp,
+                           ptr(G), cexp, stream()))
+    assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref) < 3e-6
 
 
 STREAM_CASES = [  # (state_dict prefix, cin, cout, res, ups, h, w, batch): the instances ir_stream.hip builds
