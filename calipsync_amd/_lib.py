@@ -65,6 +65,9 @@ _PROTOS = {
     "casync_op_ir_fused_up": (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, C.c_int, c_f32p, c_f32p, c_f32p,
                                         c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "casync_op_ir_fused_upg": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                         c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p]),
     "casync_op_im2col3x3": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_void_p]),
     "casync_op_upsample2x": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -86,8 +86,9 @@ struct CasyncOptions {
   int fuse_up = 1;           // CASYNC_FUSE_UP: bilinear upsample folded into up3/up4
   int fuse_min_hw = 32;      // CASYNC_FUSE_MIN_HW: lowest resolution the fused kernel is used at
   int fuse_q = 1;            // CASYNC_FUSE_Q: query projection as 64 extra columns of the p_1 GEMM
-  int ups_commute = 1;       // CASYNC_UPS_COMMUTE: Up blocks run the upsampled half of their expand conv at the low resolution
-                             //   (upsample and 1x1 conv commute), fp32; 0 = upsample first, as the reference writes it
+  int ups_commute = 2;       // CASYNC_UPS_COMMUTE: Up blocks run the upsampled half of their expand conv at the low resolution
+                             //   (upsample and 1x1 conv commute), fp32: 1 = the unfused blocks up1.0 / up2.0, 2 = also inside
+                             //   the fused kernel (up3.0 / up4.0); 0 = upsample first, as the reference writes it
   int fuse_dw = 1;           // CASYNC_FUSE_DW: expand GEMM + depthwise 3x3 in one kernel below 32x32 (pw_dw.hip), fp32
   int ir_stream = 0;         // CASYNC_IR_STREAM: row-streaming fused block (ir_stream.hip; experimental builds only): 1 = where
                              //   it beats the tile kernel in isolation, 2 = every shape it has an instance for
@@ -231,6 +232,11 @@ int launch_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, int 
                        const float* b1, const float* wd, const float* bd, const void* w2,
                        const float* b2, void* out, int ld_out, int batch, int h, int w, int cin,
                        int cout, hipStream_t stream, int dtype = DT_F32);
+// the Up block with the upsample commuted behind the expand conv (fp32): g = W1a * lo at the low resolution
+int launch_ir_fused_upg(const float* g, int ld_g, const float* in, int ld_in, const float* w1, const float* b1,
+                        const float* wd, const float* bd, const float* w2, const float* b2, float* out, int ld_out,
+                        int batch, int h, int w, int cin, int cout, hipStream_t stream);
+const char* ir_fused_upg_kernel_name(int cin, int cout);
 // w1 / w2 are in the call's storage type (fp32 or bf16); b1, wd, bd, b2 are always fp32
 int launch_ir_fused(const void* in, int ld_in, const void* w1, const float* b1, const float* wd,
                     const float* bd, const void* w2, const float* b2, void* out, int ld_out,

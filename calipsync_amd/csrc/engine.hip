@@ -635,6 +635,21 @@ struct Plan {
         gemm(std::string(b0.prefix) + ".pw1a", lo, c, std::string(b0.prefix) + ".pw1a.w", ar[A::UG], b0.cexp(),
              (long long)B * hw * hw, b0.cexp(), c, GemmEpilogue(), "-", 2.0 * B * hw * hw * (double)c * b0.cexp());
         ir(b0, cat[i] + c, cc, T0, b0.cout, E1, E2, nullptr, ar[A::UG]);
+      } else if (o.ups_commute >= 2 && dt() == DT_F32 && up_is_fused(o, b0)) {
+        // the same commutation inside the fused kernel: G = W1a * lo by a GEMM at the low resolution, the fused
+        // block runs its expand over the skip half only and adds up(G) chunk by chunk from LDS
+        const std::string p = b0.prefix;
+        const double m = (double)B * 4 * hw * hw;
+        gemm(p + ".pw1a", lo, c, p + ".pw1a.w", ar[A::UG], b0.cexp(), (long long)B * hw * hw, b0.cexp(), c, GemmEpilogue(), "-",
+             2.0 * B * hw * hw * (double)c * b0.cexp());
+        r.run((p + ".upfused").c_str(), ir_fused_upg_kernel_name(b0.cin, b0.cout),
+              2.0 * m * (c * b0.cexp() + 9.0 * b0.cexp() + b0.cexp() * b0.cout),
+              4.0 * (m / 4 * b0.cexp() + m * c + m * b0.cout), [&] {
+                return launch_ir_fused_upg((const float*)ar[A::UG].p, b0.cexp(), (const float*)(cat[i] + c).p, cc,
+                                           e.W(p + ".pw1b.w"), e.W(p + ".pw1.b"), e.W(p + ".dw.w"), e.W(p + ".dw.b"),
+                                           e.W(p + ".pw2.w"), e.W(p + ".pw2.b"), (float*)T0.p, b0.cout, B, 2 * hw,
+                                           2 * hw, b0.cin, b0.cout, r.s);
+              });
       } else if (up_is_fused(o, b0)) {
         // bilinear x2 folded into the fused block's input load: up(x) is never materialised
         const std::string p = b0.prefix;
@@ -1141,6 +1156,12 @@ int casync_op_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, i
                           int cout, casync_stream stream) {
   return launch_ir_fused_up(lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out, batch, h, w, cin,
                             cout, (hipStream_t)stream, g_op_dtype);
+}
+int casync_op_ir_fused_upg(const float* g, int ld_g, const float* in, int ld_in, const float* w1b, const float* b1,
+                           const float* wd, const float* bd, const float* w2, const float* b2, float* out, int ld_out,
+                           int batch, int h, int w, int cin, int cout, casync_stream stream) {
+  return launch_ir_fused_upg(g, ld_g, in, ld_in, w1b, b1, wd, bd, w2, b2, out, ld_out, batch, h, w, cin, cout,
+                             (hipStream_t)stream);
 }
 int casync_op_im2col3x3(const void* in, void* out, int batch, int h, int wdt, int c, int stride,
                         int pad, casync_stream stream) {

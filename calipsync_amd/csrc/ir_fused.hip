@@ -54,7 +54,7 @@ __device__ __forceinline__ bool halo_px(int t, int l15, int& hy, int& hx) {
   return hy < G::IH;
 }
 
-template <int CIN, int COUT, int STRIDE, int CC>
+template <int CIN, int COUT, int STRIDE, int CC, bool UPG = false>
 struct IRGeom {
   static constexpr int TH = STRIDE == 1 ? 8 : 4;
   static constexpr int OP = TH * TW;                        // output pixels per tile
@@ -87,9 +87,16 @@ struct IRGeom {
   // from a copy of the tile's centre pixels parked in LDS next to the staging area (written from the A fragments,
   // which hold exactly those values), instead of reading it from HBM a second time (it had left L2 by then:
   // PMC traffic of these kernels was 1.54 x algorithmic)
-  static constexpr bool RESC = STRIDE == 1 && CIN == COUT;
+  static constexpr bool RESC = STRIDE == 1 && CIN == COUT && !UPG;
   static constexpr int oX = OP * LDO;
-  static constexpr int loop_total = oW + 2 * WBUF;
+  // UPG (the commuted upsample, see ir_fused_kernel): the low-resolution tile of G = W1a * lo under this halo, one
+  // CC-channel slice per chunk, double buffered like the weights.  A 10 x 18 halo reaches at most 7 x 11 low-res
+  // pixels: its first taps span floor(9 s) + 1 = 5 rows / floor(17 s) + 1 = 9 columns (s = (n/2 - 1) / (n - 1)
+  // < 1/2), plus the second tap of the last one.
+  static constexpr int GH = 7, GW = 11, GBUF = GH * GW * CC;
+  static constexpr int oG = oW + 2 * WBUF;
+  static constexpr int NWG = (GH * GW * CC / 4 + 255) / 256;
+  static constexpr int loop_total = oG + (UPG ? 2 * GBUF : 0);
   static constexpr int total = RESC && oX + OP * CIN > loop_total ? oX + OP * CIN : loop_total;
   static_assert(OP * LDO <= total, "epilogue staging must fit in E+D+W");
   static_assert((IH * EROW) % 4 == 0 && (OP * CC) % 4 == 0 && WBUF % 4 == 0, "16-B aligned carve");
@@ -116,26 +123,33 @@ __device__ __forceinline__ int xkey(int p) { return (p & 3) ^ (CIN >= 64 ? ((p >
 
 // Waves per SIMD the register allocator must leave room for (= co-resident workgroups per
 // CU): A fragments + both accumulator sets + ~70 registers of addressing / staging.
-template <int CIN, int COUT, int STRIDE, int CC>
+template <int CIN, int COUT, int STRIDE, int CC, bool UPG = false>
 constexpr int ir_min_waves() {
-  using G = IRGeom<CIN, COUT, STRIDE, CC>;
-  constexpr int est = 4 * (G::MT1 * G::KG + G::MT3 * G::NT3 + G::MT1 * G::NT1) + 70;
+  using G = IRGeom<CIN, COUT, STRIDE, CC, UPG>;
+  constexpr int est = 4 * (G::MT1 * G::KG + G::MT3 * G::NT3 + G::MT1 * G::NT1) + 70 + (UPG ? 3 * G::MT1 + 2 * G::NWG : 0);
+  if (UPG && G::KG >= 4) return 2;   // up3.0: ~185 registers; capped at 168 it spills 23 of them and loses 1 % end to end
   return est <= 128 ? 4 : (est <= 168 ? 3 : 2);
 }
 
-// UPS: the first c_lo input channels are not read from `in` but computed on the fly as the
+// UPS = 1: the first c_lo input channels are not read from `in` but computed on the fly as the
 // bilinear x2 (align_corners=True) upsample of `lo` [B, H/2, W/2, ld_lo] -- the decoder's
 // cat([up(x), skip]) (module/unet.py:90-96) without materialising up(x).
-template <typename T, int CIN, int CE, int COUT, int STRIDE, int CC, bool UPS>
-__global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void ir_fused_kernel(
+// UPS = 2: the same block with the upsample COMMUTED behind the expand conv.  Bilinear interpolation acts per
+// channel and the 1x1 conv per pixel, so W1 * cat(up(lo), skip) = up(W1a * lo) + W1b * skip: `lo` now holds
+// G = W1a * lo [B, H/2, W/2, ld_lo >= CE] (a plain GEMM at a quarter of the pixels), `in` / CIN are the skip half
+// alone and w1 = W1b [CE][CIN].  P1 runs over half the K and adds the interpolated G slice before the LReLU.
+template <typename T, int CIN, int CE, int COUT, int STRIDE, int CC, int UPS>
+__global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>())) void ir_fused_kernel(
     const T* __restrict__ lo, int ld_lo, int c_lo,
     const T* __restrict__ in, int ld_in, const float* __restrict__ w1,
     const float* __restrict__ b1, const float* __restrict__ wd, const float* __restrict__ bd,
     const float* __restrict__ w2, const float* __restrict__ b2, T* __restrict__ out, int ld_out,
     int H, int W, int Ho, int Wo, int res, unsigned long long* __restrict__ stamps) {
-  using G = IRGeom<CIN, COUT, STRIDE, CC>;
+  constexpr bool UPG = UPS == 2;
+  using G = IRGeom<CIN, COUT, STRIDE, CC, UPG>;
   constexpr int NCH = CE / CC;
   static_assert(CC == 16, "e_off() keys and the E row padding are worked out for 64-B pixels");
+  static_assert(!UPG || (STRIDE == 1 && sizeof(T) == 4), "the commuted form exists for the fp32 stride-1 Up blocks");
   // diagnostic only (null in every product call; tools/experiments/ir_timeline.py): shader cycles wave 0 of
   // a workgroup spends in the prologue / P1 / P2 / P3 (each including the barrier wait that ends it) / epilogue
   unsigned long long t_mark = stamps ? __builtin_amdgcn_s_memtime() : 0, t_phase[5] = {0, 0, 0, 0, 0};
@@ -159,8 +173,42 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
   // does the halo leave the image?  (workgroup-uniform)
   const bool border = iy0 < 0 || ix0 < 0 || iy0 + G::IH > H || ix0 + G::IW > W;
 
+  // UPG: origin of the low-resolution G tile under this halo and this thread's 16-B pieces of one chunk slice
+  // (clamped at the bottom / right edge: the duplicates are only ever addressed as the second tap of the last
+  // row / column, where i1 == i0).  The slices go HBM -> LDS directly (global_load_lds, 16 B per lane, a wave's
+  // 64 pieces land contiguously), a chunk ahead of their use.
+  [[maybe_unused]] float* sG = smem + G::oG;
+  [[maybe_unused]] int gy0 = 0, gx0 = 0;
+  [[maybe_unused]] const T* gsrc[G::NWG];
+  if constexpr (UPG) {
+    const int Hl = H >> 1, Wl = W >> 1;
+    const float sy = (float)(Hl - 1) / (float)(H - 1), sx = (float)(Wl - 1) / (float)(W - 1);
+    gy0 = ups_tap(sy, iy0 < 0 ? 0 : iy0, Hl).i0;
+    gx0 = ups_tap(sx, ix0 < 0 ? 0 : ix0, Wl).i0;
+#pragma unroll
+    for (int j = 0; j < G::NWG; ++j) {
+      const int idx = tid + 256 * j, p = idx / (CC / 4), c4 = (idx - p * (CC / 4)) * 4;
+      const int py = p / G::GW, px = p - py * G::GW;
+      const int gy = gy0 + py < Hl ? gy0 + py : Hl - 1, gx = gx0 + px < Wl ? gx0 + px : Wl - 1;
+      gsrc[j] = lo + ((size_t)(b * Hl + gy) * Wl + gx) * ld_lo + c4;
+    }
+  }
+
   // ---- weight chunk: global -> registers (wload) and registers -> LDS (wstore) ----
   f32x4 rw1[G::NW1], rw2[G::NW2], rwd[G::NWD];
+  auto gload = [&](int ce0, int buf) {
+    if constexpr (UPG) {
+#pragma unroll
+      for (int j = 0; j < G::NWG; ++j)
+        if (tid + 256 * j < G::GBUF / 4)
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gsrc[j] + ce0),
+                                           (void __attribute__((address_space(3)))*)(sG + buf * G::GBUF + (256 * j + 64 * wave) * 4),
+                                           16, 0, 0);
+    }
+  };
+  auto gwait = [&]() {   // every request of this wave has landed (its G pieces are in LDS)
+    if constexpr (UPG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
   auto wload = [&](int ce0) {
 #pragma unroll
     for (int j = 0; j < G::NW1; ++j) {
@@ -211,6 +259,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
     }
   };
 
+  gload(0, 0);
   wload(0);
   // ---- A fragments of this wave's halo rows: HBM -> registers, once (zeros outside the image;
   //      MFMA pad rows >= HP are zero too and never stored) ----
@@ -222,7 +271,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
     const int iy = iy0 + hy, ix = ix0 + hx;
     const bool ok = live && iy >= 0 && iy < H && ix >= 0 && ix < W;
     const T* src = inb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * ld_in + 4 * q;
-    if constexpr (UPS) {
+    if constexpr (UPS == 1) {
       // same arithmetic as upsample2x_kernel / ATen: src = dst*(in-1)/(out-1), l1 = frac, l0 = 1-l1
       const int Hl = H >> 1, Wl = W >> 1;
       const float sy = (float)(Hl - 1) / (float)(H - 1), sx = (float)(Wl - 1) / (float)(W - 1);
@@ -255,6 +304,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
     }
   }
   wstore(0);
+  gwait();
   if (NCH > 1) wload(CC);
   __syncthreads();
   mark(0);
@@ -278,6 +328,25 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
     ein[i] = !border || (iy >= 0 && iy < H && ix >= 0 && ix < W);
 #pragma unroll
     for (int n = 0; n < G::NT1; ++n) ewr[i][n] = live ? e_off<STRIDE, CC, G::IW>(hy, hx, 4 * n + q) : -1;
+  }
+  // UPG: the four taps of each of this lane's halo pixels in the G tile (float offset of the first one; bits 14 / 15:
+  // whether the second column / row is a different one) and the two interpolation weights
+  [[maybe_unused]] int go[G::MT1];
+  [[maybe_unused]] float gly[G::MT1], glx[G::MT1];
+  if constexpr (UPG) {
+    const int Hl = H >> 1, Wl = W >> 1;
+    const float sy = (float)(Hl - 1) / (float)(H - 1), sx = (float)(Wl - 1) / (float)(W - 1);
+#pragma unroll
+    for (int i = 0; i < G::MT1; ++i) {
+      int hy, hx;
+      const bool live = halo_px<G>(wave * G::MT1 + i, l15, hy, hx);
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = live && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const UpsTap ty = ups_tap(sy, ok ? iy : (iy0 < 0 ? 0 : iy0), Hl), tx = ups_tap(sx, ok ? ix : (ix0 < 0 ? 0 : ix0), Wl);
+      go[i] = (((ty.i0 - gy0) * G::GW + (tx.i0 - gx0)) * CC + 4 * q) | (tx.i1 - tx.i0) << 14 | (ty.i1 - ty.i0) << 15;
+      gly[i] = ty.l1;
+      glx[i] = tx.l1;
+    }
   }
   constexpr int P2_TPP = CC / 4, P2_PPI = 256 / P2_TPP, P2_NPX = G::OP / P2_PPI;
   static_assert(P2_PPI % TW == 0 && G::TH % P2_NPX == 0, "P2 thread map");
@@ -319,14 +388,24 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
       for (int i = 0; i < G::MT1; ++i) {
         if (ewr[i][0] >= 0) {
 #pragma unroll
-          for (int n = 0; n < G::NT1; ++n)
-            *reinterpret_cast<f32x4*>(sE + ewr[i][n]) = ein[i] ? lrelu4(acc[i][n]) : f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int n = 0; n < G::NT1; ++n) {
+            f32x4 v = acc[i][n];
+            if constexpr (UPG) {   // + up(G)[pixel][these four channels]
+              const float* g0 = sG + (ch & 1) * G::GBUF + (go[i] & 0x3fff) + 16 * n;
+              const int dx = (go[i] >> 14 & 1) * CC, dy = (go[i] >> 15) * (G::GW * CC);
+              const UpsTap ty{0, 0, 1.f - gly[i], gly[i]}, tx{0, 0, 1.f - glx[i], glx[i]};
+              v += ups_lerp(ty, tx, *reinterpret_cast<const f32x4*>(g0), *reinterpret_cast<const f32x4*>(g0 + dx),
+                            *reinterpret_cast<const f32x4*>(g0 + dy), *reinterpret_cast<const f32x4*>(g0 + dy + dx));
+            }
+            *reinterpret_cast<f32x4*>(sE + ewr[i][n]) = ein[i] ? lrelu4(v) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
         }
       }
     }
     __syncthreads();  // E complete; every wave is done with the previous chunk's P3
     mark(1);
     if (ch + 1 < NCH) {
+      gload((ch + 1) * CC, (ch + 1) & 1);         // UPG: the next chunk's G slice, straight into LDS
       wstore((ch + 1) & 1);                       // park the next chunk's weights
       if (ch + 2 < NCH) wload((ch + 2) * CC);     // and start fetching the one after
     }
@@ -362,7 +441,8 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC>())) void 
         *reinterpret_cast<f32x4*>(sD + xs<CC>((py0 + j) * TW + px, c4)) = lrelu4(a[j]);
       }
     }
-    __syncthreads();  // D complete (and the parked weights are visible)
+    gwait();
+    __syncthreads();  // D complete (and the parked weights / the G slice are visible)
     mark(2);
 
     // ---- P3: project GEMM, acc3[OP x COUT] += D[OP x CC] x W2c^T ----
@@ -761,11 +841,11 @@ int launch_inst_b(const bf16_t* lo, int ld_lo, int c_lo, const bf16_t* in, int l
   return CASYNC_OK;
 }
 
-template <typename T, int CIN, int CE, int COUT, int STRIDE, int CC, bool UPS>
+template <typename T, int CIN, int CE, int COUT, int STRIDE, int CC, int UPS>
 int launch_inst_t(const T* lo, int ld_lo, int c_lo, const T* in, int ld_in, const float* w1, const float* b1,
                   const float* wd, const float* bd, const float* w2, const float* b2, T* out, int ld_out,
                   int batch, int h, int w, int res, hipStream_t stream) {
-  using G = IRGeom<CIN, COUT, STRIDE, CC>;
+  using G = IRGeom<CIN, COUT, STRIDE, CC, UPS == 2>;
   constexpr size_t lds = (size_t)G::total * sizeof(float);
   auto kern = ir_fused_kernel<T, CIN, CE, COUT, STRIDE, CC, UPS>;
   static unsigned long long attr_once = 0;
@@ -787,7 +867,7 @@ int launch_inst(int dtype, const void* lo, int ld_lo, int c_lo, const void* in, 
     return launch_inst_b<CIN, CE, COUT, STRIDE, UPS>((const bf16_t*)lo, ld_lo, c_lo, (const bf16_t*)in, ld_in,
                                                      (const bf16_t*)w1, b1, wd, bd, (const bf16_t*)w2, b2,
                                                      (bf16_t*)out, ld_out, batch, h, w, res, stream);
-  return launch_inst_t<float, CIN, CE, COUT, STRIDE, CC, UPS>((const float*)lo, ld_lo, c_lo, (const float*)in,
+  return launch_inst_t<float, CIN, CE, COUT, STRIDE, CC, UPS ? 1 : 0>((const float*)lo, ld_lo, c_lo, (const float*)in,
                                                               ld_in, (const float*)w1, b1, wd, bd, (const float*)w2,
                                                               b2, (float*)out, ld_out, batch, h, w, res, stream);
 }
@@ -841,6 +921,30 @@ int launch_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, int 
   return CASYNC_ERR_ARG;
 }
 
+// The same decoder block with the upsample commuted behind the expand conv (ir_fused_kernel, UPS = 2): g = W1a * lo
+// [batch, h/2, w/2, ld_g >= 2 * cin], `in` = the skip half (cin/2 channels), w1 = W1b [2 * cin][cin / 2].  fp32 only.
+int launch_ir_fused_upg(const float* g, int ld_g, const float* in, int ld_in, const float* w1, const float* b1,
+                        const float* wd, const float* bd, const float* w2, const float* b2, float* out, int ld_out,
+                        int batch, int h, int w, int cin, int cout, hipStream_t stream) {
+  CASYNC_REQUIRE(g && in && w1 && b1 && wd && bd && w2 && b2 && out, "ir_fused_upg: null pointer");
+  CASYNC_REQUIRE(batch > 0 && batch <= 65535 && h > 2 && w > 2 && h % 2 == 0 && w % 2 == 0, "ir_fused_upg: bad shape");
+  CASYNC_REQUIRE(ld_g >= 2 * cin && ld_g % 4 == 0 && ld_in >= cin / 2 && ld_in % 4 == 0 && ld_out >= cout && ld_out % 4 == 0,
+                 "ir_fused_upg: bad ld");
+  CASYNC_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)g % 16) == 0, "ir_fused_upg: alignment");
+  if (cin == 64 && cout == 32)
+    return launch_inst_t<float, 32, 128, 32, 1, 16, 2>(g, ld_g, 0, in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out, batch, h, w, 0, stream);
+  if (cin == 128 && cout == 32)
+    return launch_inst_t<float, 64, 256, 32, 1, 16, 2>(g, ld_g, 0, in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out, batch, h, w, 0, stream);
+  casync_set_error("ir_fused_upg: no instance for cin=%d cout=%d", cin, cout);
+  return CASYNC_ERR_ARG;
+}
+
+const char* ir_fused_upg_kernel_name(int cin, int cout) {
+  static thread_local char buf[64];
+  snprintf(buf, sizeof(buf), "ir_fused_kernel<float, %d, %d, %d, 1, 16, 2>", cin / 2, 2 * cin, cout);
+  return buf;
+}
+
 const char* ir_fused_kernel_name(int cin, int cout, int stride, int dtype, bool ups, int h, int w) {
   static thread_local char buf[64];
   if (dtype == DT_F32 && h > 0 && casync_opts().ir_stream && ir_stream_supported(cin, cout, stride, h, w, ups, cin == cout && stride == 1))
@@ -848,7 +952,7 @@ const char* ir_fused_kernel_name(int cin, int cout, int stride, int dtype, bool 
   if (dtype == DT_BF16)
     snprintf(buf, sizeof(buf), "ir_fused_bf16_kernel<%d, %d, %d, %d, %s>", cin, 2 * cin, cout, stride, ups ? "true" : "false");
   else
-    snprintf(buf, sizeof(buf), "ir_fused_kernel<float, %d, %d, %d, %d, 16, %s>", cin, 2 * cin, cout, stride, ups ? "true" : "false");
+    snprintf(buf, sizeof(buf), "ir_fused_kernel<float, %d, %d, %d, %d, 16, %d>", cin, 2 * cin, cout, stride, ups ? 1 : 0);
   return buf;
 }
 

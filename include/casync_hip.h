@@ -198,6 +198,14 @@ int casync_op_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, i
                           const void* w1, const float* b1, const float* wd, const float* bd,
                           const void* w2, const float* b2, void* out, int ld_out, int batch,
                           int h, int w, int cin, int cout, casync_stream stream);
+/* The same block with the upsample COMMUTED behind the expand conv (fp32 only): bilinear interpolation is linear
+ * per channel and the 1x1 conv linear per pixel, so W1 . cat(up(lo), skip) = up(W1a . lo) + W1b . skip.
+ * g = W1a . lo [B,h/2,w/2,ld_g >= 2*cin] (no bias), in = the skip half [B,h,w,ld_in >= cin/2], w1b [2*cin][cin/2];
+ * cin is the block's logical input width (64 / 128).  Same result as casync_op_ir_fused_up up to fp32 rounding. */
+int casync_op_ir_fused_upg(const float* g, int ld_g, const float* in, int ld_in, const float* w1b,
+                           const float* b1, const float* wd, const float* bd, const float* w2,
+                           const float* b2, float* out, int ld_out, int batch, int h, int w, int cin,
+                           int cout, casync_stream stream);
 /* im2col for the two dense 3x3 stride-2 convs (module/unet.py:161-168):
  * out[B*Ho*Wo][9*C], column order (ky,kx,c).                                */
 int casync_op_im2col3x3(const void* in, void* out, int batch, int h, int wdt, int c,

@@ -355,6 +355,46 @@ def test_ir_fused_with_upsample(lib, recipe_sd, prefix, cin, h):
     assert rel_err(nchw(out), ref) < 5e-6
 
 
+@pytest.mark.parametrize("prefix,cin,h,w,b", [
+    ("up4.conv.double_conv.0", 64, 48, 32, 2), ("up4.conv.double_conv.0", 64, 160, 160, 1), ("up4.conv.double_conv.0", 64, 20, 52, 3),
+    ("up3.conv.double_conv.0", 128, 32, 48, 2), ("up3.conv.double_conv.0", 128, 80, 80, 1)])
+def test_ir_fused_with_commuted_upsample(lib, recipe_sd, prefix, cin, h, w, b):
+    """The fused Up block with the upsample commuted behind the expand conv (casync_op_ir_fused_upg): G = W1a . lo by the
+    plain GEMM at the low resolution, the fused kernel runs over the skip half and adds up(G) from LDS.  Against the oracle
+    (the reference's order: interpolate, cat, conv; module/unet.py:90-97) and against the upsample-on-load kernel; sizes
+    with ragged tiles (20 x 52), the product sizes (160 / 80) and strided operands."""
+    from oracle import unet_oracle
+    sd = unet_oracle.to_torch(recipe_sd)
+    f = pack.fold(recipe_sd)
+    g = torch.Generator().manual_seed(cin + h)
+    c_lo, cexp = cin // 2, 2 * cin
+    lo = torch.randn(b, c_lo, h // 2, w // 2, generator=g)
+    skip = torch.randn(b, cin - c_lo, h, w, generator=g)
+    up = F.interpolate(lo, scale_factor=2, mode="bilinear", align_corners=True)
+    ref = unet_oracle.inverted_residual(sd, prefix, torch.cat([up, skip], 1), 1, False)
+    cat = torch.full((b, h, w, cin), 77.0)                   # upsampled half is never materialised
+    cat[..., c_lo:] = skip.permute(0, 2, 3, 1)
+    cat, lod = cat.to(dev()), nhwc(lo)
+    T = lambda k: torch.from_numpy(f[f"{prefix}.{k}"].astype(np.float32)).contiguous().to(dev())
+    w1, b1, wd, bd, w2, b2 = T("pw1.w"), T("pw1.b"), T("dw.w"), T("dw.b"), T("pw2.w"), T("pw2.b")
+    w1a, w1b = T("pw1a.w"), T("pw1b.w")
+    assert torch.equal(torch.cat([w1a, w1b], 1), w1)
+    ld_g = cexp + 16
+    G = torch.full((b * (h // 2) * (w // 2), ld_g), 55.0, device=dev())
+    ok(lib.casync_op_pw_gemm(ptr(lod), c_lo, ptr(w1a), 0, ptr(G), ld_g, G.shape[0], cexp, c_lo, 0, 0, 0, 0, 0, 0, 0, 0, stream()))
+    out = torch.full((b, h, w, 48), -5.0, device=dev())
+    ok(lib.casync_op_ir_fused_upg(ptr(G), ld_g, cat.data_ptr() + c_lo * 4, cin, ptr(w1b), ptr(b1), ptr(wd), ptr(bd), ptr(w2),
+                                  ptr(b2), out.data_ptr() + 16 * 4, 48, b, h, w, cin, 32, stream()))
+    o = out.cpu()
+    assert (o[..., :16] == -5).all()
+    got = o[..., 16:].permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < 5e-6, rel_err(got, ref)
+    old = torch.empty(b, h, w, 32, device=dev())
+    ok(lib.casync_op_ir_fused_up(ptr(lod), c_lo, c_lo, ptr(cat), cin, ptr(w1), ptr(b1), ptr(wd), ptr(bd), ptr(w2),
+                                 ptr(b2), ptr(old), 32, b, h, w, cin, 32, stream()))
+    assert rel_err(got, nchw(old)) < 3e-6
+
+
 @pytest.mark.parametrize("hw,stride,cin,cexp,frames", [
     (10, 1, 512, 1024, 5), (10, 1, 1024, 2048, 2), (10, 1, 256, 512, 33), (16, 1, 256, 512, 3), (20, 1, 256, 512, 2),
     (20, 2, 256, 512, 3), (20, 1, 128, 256, 2), (10, 1, 64, 128, 1)])
