@@ -199,7 +199,8 @@ constexpr long long kStreamKFloats = 2ll * kStreamKWgs * 128 * 64;  // two parti
 constexpr int kStreamKCounters = 256;
 constexpr long long kStreamKBytes = kStreamKFloats * 4 + kStreamKCounters * 4;
 
-const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype = DT_F32, bool concurrent = false);
+const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype = DT_F32, bool concurrent = false,
+                                bool ups = false);
 // a, w, c (and the (T) epilogue pointers) are `dtype` elements; lda/ldc in elements
 int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int m, int n, int k,
                    const GemmEpilogue& epi, hipStream_t stream, int dtype = DT_F32);

@@ -396,7 +396,7 @@ struct Plan {
     }
     epi.concurrent = concurrent ? 1 : 0;
     epi.stamps = g_gemm_stamps;
-    r.run(tag.c_str(), pw_gemm_kernel_name((int)m, n, k, epi.sk_ws != nullptr, dt(), concurrent),
+    r.run(tag.c_str(), pw_gemm_kernel_name((int)m, n, k, epi.sk_ws != nullptr, dt(), concurrent, epi.ups_src != nullptr),
           alg_flops > 0 ? alg_flops : 2.0 * m * n * k, bytes,
           [&] { return launch_pw_gemm(a, lda, w, c, ldc, (int)m, n, k, epi, r.s, dt()); });
   }

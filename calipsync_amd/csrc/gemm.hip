@@ -91,7 +91,10 @@ __device__ __forceinline__ float col_const(const float* regs, const float* mem, 
 // with bit 2 set instead (the wide kernel's 32-row slabs: the two lane halves of an MFMA C register are 4 rows apart).
 // LITE: only k.bias is held in registers; the rarely used per-column vectors (pre-residual scale, second affine) are
 // fetched where they are used (the A-stationary kernel has 128 registers of A fragments live across its epilogue).
-template <typename T, int NT, int BM, int BN, int PAD = 4, bool SWZ = false, bool LITE = false>
+// EUPS: the epilogue can add a bilinearly upsampled low-resolution tensor (GemmEpilogue::ups_src).  Compiled only into
+// pw_gemm_ups_kernel: its four extra row gathers per output row would set the register count -- and with it the
+// occupancy -- of every other GEMM instance (measured: bf16 128x128 2 -> 1 waves/SIMD, -13 % at B=512).
+template <typename T, int NT, int BM, int BN, int PAD = 4, bool SWZ = false, bool LITE = false, bool EUPS = false>
 __device__ __forceinline__ void epilogue_rows_cols(const float* Cs, int m0, int n0, int M, T* __restrict__ C, int ldc,
                                                    const GemmEpilogue& epi, int tid, const EpiCols<T>& k) {
   constexpr int CPT = V16<T>::N, TPR = BN / CPT, RPP = NT / TPR, LDC_S = BN + PAD;
@@ -108,7 +111,7 @@ __device__ __forceinline__ void epilogue_rows_cols(const float* Cs, int m0, int 
 #pragma unroll
       for (int q = 0; q < 4; ++q) v.v[e + q] = c[q] + k.bias[e + q];
     }
-    if (epi.ups_src) {
+    if constexpr (EUPS) {
       const int hw = epi.ups_h * epi.ups_w, Hl = epi.ups_h >> 1, Wl = epi.ups_w >> 1;
       const int b = m / hw, rem = m - b * hw, y = rem / epi.ups_w, x = rem - y * epi.ups_w;
       const UpsTap ty = ups_tap((float)(Hl - 1) / (float)(epi.ups_h - 1), y, Hl);
@@ -158,12 +161,12 @@ __device__ __forceinline__ void epilogue_rows_cols(const float* Cs, int m0, int 
   }
 }
 
-template <typename T, int NT, int BM, int BN, int PAD = 4, bool SWZ = false>
+template <typename T, int NT, int BM, int BN, int PAD = 4, bool SWZ = false, bool EUPS = false>
 __device__ __forceinline__ void epilogue_rows(const float* Cs, int m0, int n0, int M, T* __restrict__ C,
                                               int ldc, const GemmEpilogue& epi, int tid) {
   EpiCols<T> k;
   k.load(epi, n0 + (tid % (BN / V16<T>::N)) * V16<T>::N);
-  epilogue_rows_cols<T, NT, BM, BN, PAD, SWZ>(Cs, m0, n0, M, C, ldc, epi, tid, k);
+  epilogue_rows_cols<T, NT, BM, BN, PAD, SWZ, false, EUPS>(Cs, m0, n0, M, C, ldc, epi, tid, k);
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -362,12 +365,10 @@ __device__ __attribute__((aligned(256))) float g_zero_page[64];
 template <typename T, int BM, int BN, int NST, bool CONV>
 constexpr int glds_min_waves() { return sizeof(T) == 4 && BM == 64 && BN == 64 && NST == 2 && !CONV ? 5 : 1; }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST, bool CONV = false>
-__global__ __launch_bounds__(256, (glds_min_waves<T, BM, BN, NST, CONV>())) void pw_gemm_glds_kernel(const T* __restrict__ A, int lda,
-                                                           const T* __restrict__ W, T* __restrict__ C,
-                                                           int ldc, int M, int N, int K, int n_ntiles,
-                                                           int nwg, int dp_tiles, int sk_wgs, int sk_per,
-                                                           GemmEpilogue epi) {
+template <typename T, int BM, int BN, int WM, int WN, int NST, bool CONV, bool EUPS>
+__device__ __forceinline__ void glds_body(const T* __restrict__ A, int lda, const T* __restrict__ W, T* __restrict__ C,
+                                          int ldc, int M, int N, int K, int n_ntiles, int nwg, int dp_tiles, int sk_wgs,
+                                          int sk_per, const GemmEpilogue& epi) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int BK = ROWB / (int)sizeof(T);
   constexpr int E16 = 16 / (int)sizeof(T);
@@ -696,7 +697,7 @@ __global__ __launch_bounds__(256, (glds_min_waves<T, BM, BN, NST, CONV>())) void
           }
       }
       __syncthreads();
-      epilogue_rows<T, 256, BM / WM, BN>(Cs, m0 + h * (BM / WM), n0, M, C, ldc, epi, tid);
+      epilogue_rows<T, 256, BM / WM, BN, 4, false, EUPS>(Cs, m0 + h * (BM / WM), n0, M, C, ldc, epi, tid);
       __syncthreads();   // staging consumed before the next block / the next loads overwrite the ring
     }
   };
@@ -792,11 +793,29 @@ __global__ __launch_bounds__(256, (glds_min_waves<T, BM, BN, NST, CONV>())) void
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NST, bool CONV = false>
+__global__ __launch_bounds__(256, (glds_min_waves<T, BM, BN, NST, CONV>())) void pw_gemm_glds_kernel(
+    const T* __restrict__ A, int lda, const T* __restrict__ W, T* __restrict__ C, int ldc, int M, int N, int K, int n_ntiles,
+    int nwg, int dp_tiles, int sk_wgs, int sk_per, GemmEpilogue epi) {
+  glds_body<T, BM, BN, WM, WN, NST, CONV, false>(A, lda, W, C, ldc, M, N, K, n_ntiles, nwg, dp_tiles, sk_wgs, sk_per, epi);
+}
+// The same kernel with the upsampled addend in its epilogue (GemmEpilogue::ups_src): the expand conv of an Up block
+// whose upsampled half was computed at the low resolution (engine.hip decode(), ups_commute).
+template <typename T, int BM, int BN, int WM, int WN, int NST>
+__global__ __launch_bounds__(256) void pw_gemm_ups_kernel(
+    const T* __restrict__ A, int lda, const T* __restrict__ W, T* __restrict__ C, int ldc, int M, int N, int K, int n_ntiles,
+    int nwg, int dp_tiles, int sk_wgs, int sk_per, GemmEpilogue epi) {
+  glds_body<T, BM, BN, WM, WN, NST, false, true>(A, lda, W, C, ldc, M, N, K, n_ntiles, nwg, dp_tiles, sk_wgs, sk_per, epi);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NST, bool CONV = false, bool EUPS = false>
 int launch_glds_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, int k,
                   const GemmEpilogue& epi, hipStream_t stream, bool use_sk) {
   constexpr size_t lds = (size_t)NST * (BM + BN) * ROWB;
   static unsigned long long attr_once = 0;
-  auto kern = pw_gemm_glds_kernel<T, BM, BN, WM, WN, NST, CONV>;
+  auto kern = [] {
+    if constexpr (EUPS) return pw_gemm_ups_kernel<T, BM, BN, WM, WN, NST>;
+    else return pw_gemm_glds_kernel<T, BM, BN, WM, WN, NST, CONV>;
+  }();
   if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)lds)) return st;
   const int n_mtiles = (m + BM - 1) / BM, n_ntiles = n / BN;
   const long long nwg = (long long)n_mtiles * n_ntiles;
@@ -995,8 +1014,9 @@ int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullp
 }  // namespace
 
 // Name of the kernel instance launch_pw_gemm() will pick (as rocprofv3 prints it).
-const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype, bool concurrent) {
+const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype, bool concurrent, bool ups) {
   static thread_local char buf[64];
+  if (ups) return "pw_gemm_ups_kernel<float, 64, 64, 2, 2, 2>";
   const char* t = dtype == DT_BF16 ? "__bf16" : "float";
   const int id = pick_cfg(m, n, k, stream_k, dtype, nullptr, concurrent);
   const char* cfg;
@@ -1045,6 +1065,11 @@ int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int 
                      (!epi.acc_out || ((uintptr_t)epi.acc_out % 16 == 0 && (uintptr_t)epi.acc_in % 16 == 0)),
                  "pw_gemm: residual pointers must be 16-B aligned");
   bool sk = false;
+  if (epi.ups_src) {   // one instance carries the upsampled addend: fp32, the 64x64 two-stage ring
+    CASYNC_REQUIRE(dtype == DT_F32 && n % 64 == 0, "pw_gemm: the upsampled addend needs fp32 and N %% 64 == 0 (N=%d)", n);
+    return launch_glds_t<float, 64, 64, 2, 2, 2, false, true>(static_cast<const float*>(a), lda, static_cast<const float*>(w),
+                                                              static_cast<float*>(c), ldc, m, n, k, epi, stream, false);
+  }
   switch (pick_cfg(m, n, k, epi.sk_ws != nullptr, dtype, &sk, epi.concurrent != 0)) {
     case C128x128: return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
     case C128x64: return launch_cfg<128, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
