@@ -1,0 +1,65 @@
+"""Static resource budget of the built gfx950 kernels (no GPU): nothing spills, and the kernels the bench lines rest on
+keep the waves-per-SIMD class they were tuned at.  Numeric tests cannot see this: a feature added to the shared GEMM
+epilogue once raised the register count of EVERY instance (bf16 128x128: 2 -> 1 waves/SIMD, -13 % at B=512; the
+dominant fp32 64x64 ring kernel: 48 B of scratch) with every parity test green."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import kernel_resources  # noqa: E402
+
+from calipsync_amd import build  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not kernel_resources.tools_available(), reason="llvm binutils of the ROCm image not found")
+
+# kernel -> lowest waves per SIMD it may be built for (= co-resident workgroups of 4 waves per CU, registers permitting)
+MIN_WAVES = {
+    "pw_gemm_glds_kernel<float, 64, 64, 2, 2, 2, false>": 5,     # dominant fp32 kernel: five 32-KB rings share a CU
+    "pw_gemm_glds_kernel<float, 64, 64, 2, 2, 2, true>": 4,      # implicit-GEMM 3x3 conv
+    "pw_gemm_glds_kernel<float, 128, 64, 2, 2, 2, false>": 3,
+    "pw_gemm_ups_kernel<float, 64, 64, 2, 2, 2>": 4,
+    "pw_gemm_kernel<float, 64, 64, 2, 2>": 4,
+    "pw_gemm_kernel<float, 128, 32, 4, 1>": 4,
+    "pw_gemm_kernel<__bf16, 128, 128, 2, 2>": 2,                 # dominant bf16 kernel (B=512)
+    "pw_gemm_kernel<__bf16, 128, 64, 2, 2>": 3,
+    "pw_gemm_glds_kernel<__bf16, 64, 64, 2, 2, 2, false>": 4,
+    "ir_fused_kernel<float, 32, 64, 32, 1, 16, 0>": 4,           # up3.1 / up4.1
+    "ir_fused_kernel<float, 64, 128, 32, 1, 16, 0>": 3,
+    "ir_fused_kernel<float, 32, 128, 32, 1, 16, 2>": 3,          # up4.0, upsample commuted
+    "ir_fused_kernel<float, 64, 256, 32, 1, 16, 2>": 2,          # up3.0, upsample commuted
+    "ir_fused_kernel<float, 64, 128, 64, 1, 16, 0>": 3,          # down1.1
+    "ir_fused_kernel<float, 32, 64, 64, 2, 16, 0>": 3,           # down1.0
+    "ir_fused_bf16_kernel<64, 128, 32, 1, true>": 4,
+    "ir_fused_bf16_kernel<32, 64, 32, 1, false>": 5,
+    "pw_dw_kernel<10, 2, 32, 16>": 8,
+    "pw_dw_kernel<20, 1, 32, 16>": 5,
+    "inc_kernel<float>": 4,
+    "outc_kernel<float>": 4,
+}
+
+
+@pytest.fixture(scope="module")
+def table():
+    build.build()                      # no-op when the library is up to date
+    if build.EXPERIMENTAL:
+        pytest.skip("budgets are pinned for the product build")
+    return kernel_resources.table()
+
+
+def test_every_kernel_is_listed(table):
+    assert len(table) >= 60
+    missing = [k for k in MIN_WAVES if k not in table]
+    assert not missing, f"kernels renamed or dropped (update MIN_WAVES): {missing}"
+
+
+def test_no_kernel_spills(table):
+    spilling = {k: v["scratch"] for k, v in table.items() if v["scratch"]}
+    assert not spilling, f"kernels with scratch (register spills), bytes per lane: {spilling}"
+
+
+def test_tuned_kernels_keep_their_occupancy(table):
+    low = {k: (table[k]["vgprs"], table[k]["waves"], want) for k, want in MIN_WAVES.items() if table[k]["waves"] < want}
+    assert not low, f"(registers, waves/SIMD now, waves/SIMD pinned): {low}"
