@@ -437,6 +437,7 @@ def main():
                 print(f"  {r['name']:48s} {r['kernel']:38s} {r['ms']:8.3f} ms {r['flops'] / max(r['ms'], 1e-6) / 1e9:8.1f} TF "
                       f"{r['bytes'] / max(r['ms'], 1e-6) / 1e6:8.1f} GB/s", file=sys.stderr)
         dom_name, dom = max(per.items(), key=lambda kv: kv[1]["ms"])
+        executed_flops = sum(c["flops"] for c in per.values()) / reps      # of one B-frame forward, as launched
         tf = dom["flops"] / dom["ms"] / 1e9
         gbs = dom["bytes"] / dom["ms"] / 1e6
         mfma_peak = MFMA_F32_PEAK_TF if args.dtype == "f32" else MFMA_BF16_PEAK_TF
@@ -522,6 +523,11 @@ def main():
             "whole_net": {"mfma_frac": round(per_gpu * work["flops"] / (mfma_peak * 1e12), 4),
                           "hbm_frac_canonical": round(per_gpu * canon_bytes / (HBM_PEAK_GBS * 1e9), 4),
                           "gflop_per_frame": round(work["flops"] / 1e9, 3),
+                          # mfma_frac is quoted on the REFERENCE's flops.  The engine executes fewer: with
+                          # ups_commute the upsampled half of every Up block's expand conv runs at a quarter of the pixels
+                          # (up(W1a.lo) = W1a.up(lo)).  What the matrix pipes actually did:
+                          "executed_gflop_per_frame": round(executed_flops / B / 1e9, 3),
+                          "mfma_frac_executed": round(per_gpu * executed_flops / B / (mfma_peak * 1e12), 4),
                           "canonical_mb_per_frame": round(canon_bytes / 1e6, 2),
                           # per stage max(canonical bytes / 8 TB/s, flops / matrix peak), summed
                           "stagewise_bound_fps_per_gpu": round(stage["frames_per_s"], 1),

@@ -455,9 +455,9 @@ struct Plan {
     // (from 16 frames per launch: below that its whole-frame tiles are too few to fill the chip -- B=1 0.92 vs 0.82 ms)
     if (dt() == DT_F32 && o.fuse_dw && B >= 16 && pw_dw_supported(b.hw_in, k_in, b.cexp(), b.stride)) {
       // expand GEMM whose output tile is whole frames: the depthwise conv runs on the tile in LDS, E never exists
-      // (flops: the reference's own formulation, whatever half of it runs at the low resolution)
+      // (flops: what this launch executes -- with `ups` the upsampled half was a GEMM at the low resolution)
       r.run((p + ".pw1dw").c_str(), pw_dw_kernel_name(b.hw_in, b.cexp(), B),
-            2.0 * (m_in * (double)(ups.p ? b.cin * 5 / 8.0 : b.cin) * b.cexp() + 9.0 * m_out * b.cexp()),
+            2.0 * (m_in * (double)k_in * b.cexp() + 9.0 * m_out * b.cexp()),
             4.0 * (m_in * (double)k_in + (double)b.cexp() * k_in + (double)m_out * b.cexp()), [&] {
         return launch_pw_dw(in, ld_in, e.W(w1name), e.W(p + ".pw1.b"), e.W(p + ".dw.w"), e.W(p + ".dw.b"), e2,
                             b.cexp(), B, b.hw_in, b.stride, k_in, b.cexp(), r.s, ups.p, b.cexp());
@@ -470,8 +470,7 @@ struct Plan {
         ep1.ups_ld = b.cexp();
         ep1.ups_h = ep1.ups_w = b.hw_in;
       }
-      gemm(p + ".pw1", in, ld_in, w1name, e1, b.cexp(), m_in, b.cexp(), k_in, ep1, p + ".pw1.b",
-           ups.p ? 2.0 * m_in * (b.cin * 5 / 8.0) * b.cexp() : 0);
+      gemm(p + ".pw1", in, ld_in, w1name, e1, b.cexp(), m_in, b.cexp(), k_in, ep1, p + ".pw1.b");
       r.run((p + ".dw").c_str(), dw3x3_kernel_name(b.hw_in, b.hw_in, b.cexp(), b.stride, dt()),
             2.0 * 9 * m_out * b.cexp(), dtype_size(dt()) * (double)(m_in + m_out) * b.cexp(), [&] {
         return launch_dw3x3(e1, e.W(p + ".dw.w"), e.W(p + ".dw.b"), e2, B, b.hw_in, b.hw_in, b.cexp(),
@@ -631,7 +630,7 @@ struct Plan {
       if (commute) {
         // upsample and 1x1 conv commute: the upsampled half of the expand conv runs on the LOW-resolution tensor
         // (a quarter of the pixels: 37.5 % of this GEMM's multiply-adds never happen), the consumer adds its bilinear
-        // x2 upsample before the activation.  Flops are booked where the reference has them (the consumer).
+        // x2 upsample before the activation.  Every launch books the flops it executes.
         gemm(std::string(b0.prefix) + ".pw1a", lo, c, std::string(b0.prefix) + ".pw1a.w", ar[A::UG], b0.cexp(),
              (long long)B * hw * hw, b0.cexp(), c, GemmEpilogue(), "-", 2.0 * B * hw * hw * (double)c * b0.cexp());
         ir(b0, cat[i] + c, cc, T0, b0.cout, E1, E2, nullptr, ar[A::UG]);
