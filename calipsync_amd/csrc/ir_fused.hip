@@ -68,6 +68,15 @@ struct IRGeom {
   static constexpr int BT = IW / 16, TAIL = IW - 16 * BT;
   static constexpr int NTILE = IH * BT + (IH * TAIL + 15) / 16;
   static constexpr int MT1 = (NTILE + 3) / 4;               // P1 M-tiles per wave
+  // is tile slot i (tile wave * MT1 + i) a whole, existing tile for every wave?  (Only the last tail tile can hold
+  // MFMA pad rows, and the slots behind NTILE do not exist.)
+  static constexpr bool slot_full(int i) {
+    for (int w = 0; w < 4; ++w) {
+      const int t = w * MT1 + i;
+      if (t >= NTILE || (t == NTILE - 1 && (IH * TAIL) % 16 != 0)) return false;
+    }
+    return true;
+  }
   static constexpr int HPP = MT1 * 64;
   // E row pitch in floats: rows are padded by 16 B so that the tails of consecutive rows (same hx, same key) fall on
   // different banks (an unpadded row is a multiple of 64 B)
@@ -329,10 +338,12 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
 #pragma unroll
     for (int n = 0; n < G::NT1; ++n) ewr[i][n] = live ? e_off<STRIDE, CC, G::IW>(hy, hx, 4 * n + q) : -1;
   }
-  // UPG: the four taps of each of this lane's halo pixels in the G tile (float offset of the first one; bits 14 / 15:
-  // whether the second column / row is a different one) and the two interpolation weights
+  // UPG: where the first of the four taps of each of this lane's halo pixels sits in the G tile, and the four corner
+  // weights.  The other taps are ALWAYS the next column / row of the tile (immediate offsets): where the reference
+  // clamps the second tap (last row / column of the image) its weight is exactly 0 and the tile holds a clamped,
+  // finite duplicate there.
   [[maybe_unused]] int go[G::MT1];
-  [[maybe_unused]] float gly[G::MT1], glx[G::MT1];
+  [[maybe_unused]] f32x4 gw[G::MT1];
   if constexpr (UPG) {
     const int Hl = H >> 1, Wl = W >> 1;
     const float sy = (float)(Hl - 1) / (float)(H - 1), sx = (float)(Wl - 1) / (float)(W - 1);
@@ -343,9 +354,8 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
       const int iy = iy0 + hy, ix = ix0 + hx;
       const bool ok = live && iy >= 0 && iy < H && ix >= 0 && ix < W;
       const UpsTap ty = ups_tap(sy, ok ? iy : (iy0 < 0 ? 0 : iy0), Hl), tx = ups_tap(sx, ok ? ix : (ix0 < 0 ? 0 : ix0), Wl);
-      go[i] = (((ty.i0 - gy0) * G::GW + (tx.i0 - gx0)) * CC + 4 * q) | (tx.i1 - tx.i0) << 14 | (ty.i1 - ty.i0) << 15;
-      gly[i] = ty.l1;
-      glx[i] = tx.l1;
+      go[i] = ((ty.i0 - gy0) * G::GW + (tx.i0 - gx0)) * CC + 4 * q;
+      gw[i] = f32x4{ty.l0 * tx.l0, ty.l0 * tx.l1, ty.l1 * tx.l0, ty.l1 * tx.l1};
     }
   }
   constexpr int P2_TPP = CC / 4, P2_PPI = 256 / P2_TPP, P2_NPX = G::OP / P2_PPI;
@@ -384,20 +394,23 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
 #pragma unroll
             for (int n = 0; n < G::NT1; ++n) acc[i][n] = mfma16(fb[n][s], fa[i][g][s], acc[i][n]);
       }
+      // Few tile slots can hold MFMA pad rows (IRGeom::slot_full).
+      {
 #pragma unroll
-      for (int i = 0; i < G::MT1; ++i) {
-        if (ewr[i][0] >= 0) {
+        for (int i = 0; i < G::MT1; ++i) {
+          if (G::slot_full(i) || ewr[i][0] >= 0) {
 #pragma unroll
-          for (int n = 0; n < G::NT1; ++n) {
-            f32x4 v = acc[i][n];
-            if constexpr (UPG) {   // + up(G)[pixel][these four channels]
-              const float* g0 = sG + (ch & 1) * G::GBUF + (go[i] & 0x3fff) + 16 * n;
-              const int dx = (go[i] >> 14 & 1) * CC, dy = (go[i] >> 15) * (G::GW * CC);
-              const UpsTap ty{0, 0, 1.f - gly[i], gly[i]}, tx{0, 0, 1.f - glx[i], glx[i]};
-              v += ups_lerp(ty, tx, *reinterpret_cast<const f32x4*>(g0), *reinterpret_cast<const f32x4*>(g0 + dx),
-                            *reinterpret_cast<const f32x4*>(g0 + dy), *reinterpret_cast<const f32x4*>(g0 + dy + dx));
+            for (int n = 0; n < G::NT1; ++n) {
+              f32x4 v = acc[i][n];
+              if constexpr (UPG) {   // + up(G)[pixel][these four channels]: four fused multiply-adds per channel
+                const float* g0 = sG + (ch & 1) * G::GBUF + go[i] + 16 * n;
+                v += gw[i][0] * *reinterpret_cast<const f32x4*>(g0);
+                v += gw[i][1] * *reinterpret_cast<const f32x4*>(g0 + CC);
+                v += gw[i][2] * *reinterpret_cast<const f32x4*>(g0 + G::GW * CC);
+                v += gw[i][3] * *reinterpret_cast<const f32x4*>(g0 + G::GW * CC + CC);
+              }
+              *reinterpret_cast<f32x4*>(sE + ewr[i][n]) = ein[i] ? lrelu4(v) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            *reinterpret_cast<f32x4*>(sE + ewr[i][n]) = ein[i] ? lrelu4(v) : f32x4{0.f, 0.f, 0.f, 0.f};
           }
         }
       }
