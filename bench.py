@@ -423,17 +423,20 @@ def main():
         # per-kernel durations there are not separable.  The roofline pass replays the SAME launches
         # (same lanes, hence the same kernels, tile choices and grids) serialised on one stream with
         # an event pair around each (casync_profile_forward).
-        for _ in range(reps):
-            for row in net.profile(x, a):
-                c = per.setdefault(row["kernel"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
-                c["ms"] += row["ms"]; c["flops"] += row["flops"]; c["bytes"] += row["bytes"]; c["n"] += 1
+        # every launch is timed `reps` times; its figure is the MEDIAN of those (one slow launch -- a cold instruction
+        # cache, a clock dip -- otherwise moves a whole kernel family's average), counted `reps` times so that the
+        # sums below keep their meaning
+        runs = [net.profile(x, a) for _ in range(reps)]
+        for i, row in enumerate(runs[0]):
+            ms = sorted(r[i]["ms"] for r in runs)[reps // 2]
+            c = per.setdefault(row["kernel"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
+            c["ms"] += ms * reps; c["flops"] += row["flops"] * reps; c["bytes"] += row["bytes"] * reps; c["n"] += reps
         if args.kernel_table:
             tot = sum(c["ms"] for c in per.values())
             for k, c in sorted(per.items(), key=lambda kv: -kv[1]["ms"]):
                 print(f"{k:40s} {c['n'] // reps:4d} launches {c['ms'] / reps:9.3f} ms {100 * c['ms'] / tot:5.1f}%  "
                       f"{c['flops'] / c['ms'] / 1e9:8.1f} TFLOP/s {c['bytes'] / c['ms'] / 1e6:8.1f} GB/s", file=sys.stderr)
-            rows = net.profile(x, a)
-            for r in rows:
+            for r in runs[-1]:
                 print(f"  {r['name']:48s} {r['kernel']:38s} {r['ms']:8.3f} ms {r['flops'] / max(r['ms'], 1e-6) / 1e9:8.1f} TF "
                       f"{r['bytes'] / max(r['ms'], 1e-6) / 1e6:8.1f} GB/s", file=sys.stderr)
         dom_name, dom = max(per.items(), key=lambda kv: kv[1]["ms"])
