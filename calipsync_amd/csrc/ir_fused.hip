@@ -84,7 +84,7 @@ struct IRGeom {
   static constexpr int NT1 = CC / 16;
   static constexpr int MT3 = OP / 64;                       // P3 M-tiles per wave
   static constexpr int NT3 = COUT / 16;
-  static constexpr int LDO = 36;                            // epilogue staging: 32 columns + 4
+  static constexpr int LDO = 36;                            // epilogue staging of the bf16 kernel: 32 columns + 4
   // one weight buffer: W1c [CC][CIN], W2c [COUT][CC], Wd [9][CC], b1 [CC], bd [CC]
   static constexpr int wW1 = 0, wW2 = wW1 + CC * CIN, wWd = wW2 + COUT * CC, wB = wWd + 9 * CC;
   static constexpr int WBUF = wB + 2 * CC;
@@ -93,11 +93,11 @@ struct IRGeom {
   static constexpr int oD = oE + IH * EROW;
   static constexpr int oW = oD + OP * CC;
   // stride 1 and CIN == COUT = the blocks with a residual connection (module/unet.py:14): their epilogue takes x
-  // from a copy of the tile's centre pixels parked in LDS next to the staging area (written from the A fragments,
+  // from a copy of the tile's centre pixels parked in LDS over the dead E / D / W tiles (written from the A fragments,
   // which hold exactly those values), instead of reading it from HBM a second time (it had left L2 by then:
   // PMC traffic of these kernels was 1.54 x algorithmic)
   static constexpr bool RESC = STRIDE == 1 && CIN == COUT && !UPG;
-  static constexpr int oX = OP * LDO;
+  static constexpr int oX = 0;
   // UPG (the commuted upsample, see ir_fused_kernel): the low-resolution tile of G = W1a * lo under this halo, one
   // CC-channel slice per chunk, double buffered like the weights.  A 10 x 18 halo reaches at most 7 x 11 low-res
   // pixels: its first taps span floor(9 s) + 1 = 5 rows / floor(17 s) + 1 = 9 columns (s = (n/2 - 1) / (n - 1)
@@ -107,7 +107,6 @@ struct IRGeom {
   static constexpr int NWG = (GH * GW * CC / 4 + 255) / 256;
   static constexpr int loop_total = oG + (UPG ? 2 * GBUF : 0);
   static constexpr int total = RESC && oX + OP * CIN > loop_total ? oX + OP * CIN : loop_total;
-  static_assert(OP * LDO <= total, "epilogue staging must fit in E+D+W");
   static_assert((IH * EROW) % 4 == 0 && (OP * CC) % 4 == 0 && WBUF % 4 == 0, "16-B aligned carve");
   static_assert(TAIL > 0 && TAIL <= 16, "tile walk: a partial last tile per row");
   static constexpr int KG = CIN / 16;                       // k-groups of 16: one A-fragment float4 each
@@ -117,11 +116,6 @@ struct IRGeom {
   static constexpr int NW2 = (COUT * CC / 4 + 255) / 256;
   static constexpr int NWD = (11 * CC / 4 + 255) / 256;    // Wd, b1, bd are contiguous per chunk in LDS
 };
-
-// Epilogue staging sO [OP][32 columns] of the fp32 kernel: unpadded 128-B rows, 16-B column XOR (pixel & 3).  The
-// stores come from the accumulator layout (eight consecutive pixels, one column: pairs share a bank, free for a 16-B
-// store), the loads walk whole rows (the XOR stays inside each 64-B half, so a service group's rows never meet).
-__device__ __forceinline__ int so_off(int p, int col16) { return p * 32 + ((col16 ^ (p & 3)) << 2); }
 
 // The parked residual tile sX [OP][CIN]: its stores come from the A fragments (eight consecutive lanes = eight
 // consecutive pixels, a CIN x 4 B stride: all on the same banks), its loads walk whole 128-B row slices.  XORing the
@@ -481,14 +475,15 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
     if (stamps) asm volatile("s_nop 0" :: "v"(acc3[0][0]));   // keep P3's MFMAs in front of the stamp
     mark(3);
   }
-  __syncthreads();
-
-  // ---- epilogue: + b2, LReLU -> LDS staging (over E/D/W, 32 columns at a time) -> coalesced
-  //      NHWC rows (+ residual) ----
-  float* sO = sE;
+  // ---- epilogue: + b2, LReLU (+ residual) straight from the accumulators.  A lane holds four consecutive output
+  //      channels of one pixel and the sixteen pixels of an MFMA tile are one output row segment, so a store
+  //      instruction writes sixteen consecutive pixels x 64 B: no LDS staging, no barrier -- a wave leaves as soon as
+  //      its own stores are issued.  Only the blocks with a residual connection meet once more: x of the tile's centre
+  //      pixels sits in OTHER lanes' A fragments and goes through LDS (not through HBM again: it had left L2). ----
   float* sX = smem + G::oX;
   if constexpr (G::RESC && sizeof(T) == 4) {
-    if (res) {   // park x of the tile's centre pixels: [OP][CIN], straight from the A fragments
+    if (res) {
+      __syncthreads();   // every wave is done with D / W, which the parked tile overlays
 #pragma unroll
       for (int i = 0; i < G::MT1; ++i) {
         int hy, hx;
@@ -499,29 +494,21 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
           for (int g = 0; g < G::KG; ++g) *reinterpret_cast<f32x4*>(dst + (((4 * g + q) ^ xkey<CIN>(p)) << 2)) = fa[i][g];
         }
       }
+      __syncthreads();
     }
   }
   T* outb = out + (size_t)b * Ho * Wo * ld_out;
 #pragma unroll
-  for (int n0 = 0; n0 < G::NT3; n0 += 2) {
-    if (n0) __syncthreads();  // previous slice fully stored before it is overwritten
+  for (int n = 0; n < G::NT3; ++n) {
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(b2 + 16 * n + 4 * q);
+    const int c = 16 * n + 4 * q;
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn) {
-      const f32x4 bias = *reinterpret_cast<const f32x4*>(b2 + 16 * (n0 + nn) + 4 * q);
-#pragma unroll
-      for (int i = 0; i < G::MT3; ++i) {
-        const int p = 16 * (wave * G::MT3 + i) + l15;      // acc3 rows = 4 consecutive output channels
-        *reinterpret_cast<f32x4*>(sO + so_off(p, 4 * nn + q)) = lrelu4(acc3[i][n0 + nn] + bias);
-      }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < G::OP * 8; idx += 256) {
-      const int p = idx >> 3, c4 = (idx & 7) * 4;
+    for (int i = 0; i < G::MT3; ++i) {
+      const int p = 16 * (wave * G::MT3 + i) + l15;      // acc3 rows = 4 consecutive output channels
       const int py = p / TW, px = p - py * TW;
       const int oy = oy0 + py, ox = ox0 + px;
       if (oy < Ho && ox < Wo) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(sO + so_off(p, c4 >> 2));
-        const int c = 16 * n0 + c4;
+        f32x4 v = lrelu4(acc3[i][n] + bias);
         if (res) {   // stride 1, CIN == COUT: + the block input pixel
           if constexpr (G::RESC && sizeof(T) == 4) v += *reinterpret_cast<const f32x4*>(sX + p * CIN + (((c >> 2) ^ xkey<CIN>(p)) << 2));
           else v += ld4(inb + ((size_t)oy * W + ox) * ld_in + c);
