@@ -89,7 +89,8 @@ struct CasyncOptions {
   int ups_commute = 2;       // CASYNC_UPS_COMMUTE: Up blocks run the upsampled half of their expand conv at the low resolution
                              //   (upsample and 1x1 conv commute), fp32: 1 = the unfused blocks up1.0 / up2.0, 2 = also inside
                              //   the fused kernel (up3.0 / up4.0); 0 = upsample first, as the reference writes it
-  int fuse_dw = 1;           // CASYNC_FUSE_DW: expand GEMM + depthwise 3x3 in one kernel below 32x32 (pw_dw.hip), fp32
+  int fuse_dw = 2;           // CASYNC_FUSE_DW: expand GEMM + depthwise 3x3 in one kernel (pw_dw.hip), fp32: 1 = the 10x10 / 16x16 /
+                             //   20x20 blocks (whole-frame tiles), 2 = also the 40x40 blocks (row strips)
   int ir_stream = 0;         // CASYNC_IR_STREAM: row-streaming fused block (ir_stream.hip; experimental builds only): 1 = where
                              //   it beats the tile kernel in isolation, 2 = every shape it has an instance for
   int ir_stream_min = 2;     // CASYNC_IR_STREAM_MIN: fewest steps per workgroup run of the streaming kernel
@@ -246,7 +247,7 @@ int launch_ir_fused(const void* in, int ld_in, const void* w1, const float* b1, 
 // expand 1x1 + depthwise 3x3 of a low-resolution inverted residual in one kernel (pw_dw.hip): fp32, 10x10 / 16x16 /
 // 20x20 frames; a [frames*hw*hw, lda], w1 [cexp][cin], wd [9][cexp], d [frames*ho*ho, ldd]
 bool pw_dw_supported(int hw, int cin, int cexp, int stride);
-const char* pw_dw_kernel_name(int hw, int cexp, int frames);
+const char* pw_dw_kernel_name(int hw, int cexp, int frames, int stride = 1);
 // ups (optional): low-resolution addend [frames*(hw/2)^2, ld_ups] whose bilinear x2 upsample is added before the first
 // activation (an Up block's upsampled half, see GemmEpilogue::ups_src)
 int launch_pw_dw(const void* a, int lda, const void* w1, const float* b1, const float* wd, const float* bd, void* d, int ldd,

@@ -1,5 +1,6 @@
 // Expand 1x1 conv + BN + LeakyReLU + depthwise 3x3 + BN + LeakyReLU in ONE kernel, for the inverted residuals of the
-// low-resolution stages (10x10, 16x16, 20x20: reference module/unet.py:17-30 with BN folded):
+// low-resolution stages (10x10, 16x16, 20x20 as whole-frame tiles, 40x40 as row strips -- pw_dw_strip_kernel below:
+// reference module/unet.py:17-30 with BN folded):
 //
 //   D[b, oy, ox, n] = lrelu( sum_taps wd[tap][n] * E[b, oy*s + ky - 1, ox*s + kx - 1, n] + bd[n] ),
 //   E[b, y, x, n]   = lrelu( A[b, y, x, :] . W1[n, :] + b1[n] )                    (zero outside the frame)
@@ -210,6 +211,183 @@ __global__ __launch_bounds__(256, (FTGeom<HW, F, BN, KF>::occ)) void pw_dw_kerne
   }
 }
 
+// ---- 40 x 40 frames: a whole frame does not fit a tile (1600 pixels x 32 channels = 200 KB), so the tile is a STRIP of
+// SR output rows of one frame: its (SR - 1) * STRIDE + 3 input rows x 40 columns are contiguous rows of A, the expand
+// GEMM recomputes the one-row halo of the neighbouring strips (10 rows for 8: x 1.25; stride 2: 9 for 8: x 1.125),
+// rows above / below the frame become zero rows of E (the depthwise conv zero-pads the EXPANDED tensor).  Everything
+// else is pw_dw_kernel.
+template <int HW, int SR, int STRIDE, int BN, int KF>
+struct FSGeom {
+  static constexpr int ROWB = KF * 4, RPI = 1024 / ROWB;
+  static constexpr int P = HW * HW, RIN = (SR - 1) * STRIDE + 3, M = RIN * HW, MT = (M + 15) / 16, M_PAD = 16 * MT;
+  static constexpr int HO = (HW + 2 - 3) / STRIDE + 1, NS = (HO + SR - 1) / SR;   // output rows / strips per frame
+  static constexpr int NT = BN / 16, WPN = 4 / NT;
+  static constexpr int MTW = (MT + WPN - 1) / WPN;
+  static constexpr int ROWS = M_PAD + BN, LPT = (ROWS + 4 * RPI - 1) / (4 * RPI), STAGE = LPT * 4 * RPI * ROWB;
+  static constexpr int NQ = BN / 4, PSTEP = 256 / NQ;
+  static constexpr size_t etile = (size_t)M_PAD * BN * sizeof(float);
+  static constexpr size_t lds = 2 * (size_t)STAGE > etile ? 2 * (size_t)STAGE : etile;
+  static constexpr int occ = (int)(160 * 1024 / lds) >= 4 ? 4 : (int)(160 * 1024 / lds);
+  static_assert(NT == 2 || NT == 4, "BN = 32 or 64");
+  static_assert(KF == 16 || KF == 32, "64-B or 128-B k-tile rows");
+  static_assert(lds <= 160 * 1024, "LDS budget");
+};
+
+template <int HW, int SR, int STRIDE, int BN, int KF>
+__global__ __launch_bounds__(256, (FSGeom<HW, SR, STRIDE, BN, KF>::occ)) void pw_dw_strip_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ W1, const float* __restrict__ b1,
+    const float* __restrict__ wd, const float* __restrict__ bd, float* __restrict__ D, int ldd, int frames, int K, int N,
+    int n_ntiles, int nwg, unsigned a_bytes, unsigned w_bytes, const float* __restrict__ ups, int ld_ups) {
+  using G = FSGeom<HW, SR, STRIDE, BN, KF>;
+  constexpr int ROWB = G::ROWB, RPI = G::RPI, CPR = ROWB / 16;
+  extern __shared__ __attribute__((aligned(16))) char ring[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4, lrow = lane / CPR, lcol = lane % CPR;
+
+  int ft, nt;   // XCD-aware order: the channel tiles of one strip (same A rows) meet in one L2
+  {
+    const int t = blockIdx.x, qn = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
+    const int bid = (xcd < r ? xcd * (qn + 1) : r * (qn + 1) + (xcd - r) * qn) + idx;
+    ft = bid / n_ntiles;
+    nt = bid - ft * n_ntiles;
+  }
+  const int fr = ft / G::NS, st = ft - fr * G::NS;           // frame, strip
+  const int y0 = st * SR * STRIDE - 1;                       // first input row of the strip (-1: the zero row above the frame)
+  const int row_lo = fr * G::P, row_base = row_lo + y0 * HW; // A row of strip pixel 0 (may lie before the frame)
+  const int n0 = nt * BN, nk = K / KF;
+
+  int voff[G::LPT];
+#pragma unroll
+  for (int j = 0; j < G::LPT; ++j) {
+    const int r = (j * 4 + wave) * RPI + lrow;
+    const int cs = lcol ^ ft_key<KF>(r);
+    if ((j * 4 + wave) * RPI < G::M_PAD) {
+      int row = row_base + r;                                // rows outside the frame / pad rows: any row of the frame
+      row = row < row_lo ? row_lo : (row > row_lo + G::P - 1 ? row_lo + G::P - 1 : row);
+      voff[j] = (int)((long long)row * lda * 4) + cs * 16;
+    } else {
+      const int wr = r - G::M_PAD < BN ? r - G::M_PAD : 0;
+      voff[j] = (n0 + wr) * K * 4 + cs * 16;
+    }
+  }
+  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < G::LPT; ++j) {
+      char* dst = ring + stage * G::STAGE + (j * 4 + wave) * RPI * ROWB;
+      if ((j * 4 + wave) * RPI < G::M_PAD) ft_dma16(A, a_bytes, dst, voff[j], kt * ROWB);
+      else ft_dma16(W1, w_bytes, dst, voff[j], kt * ROWB);
+    }
+  };
+
+  const int wn = wave % G::NT, wm = wave / G::NT;
+  const int key = ft_key<KF>(l15);
+  int frag[KF / 16];
+#pragma unroll
+  for (int g = 0; g < KF / 16; ++g) frag[g] = l15 * ROWB + (((4 * g + q) ^ key) << 4);
+  f32x4 acc[G::MTW];
+#pragma unroll
+  for (int i = 0; i < G::MTW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    const char* stg = ring + (kt & 1) * G::STAGE;
+    f32x4 fw[KF / 16], fa[KF / 16][G::MTW];
+#pragma unroll
+    for (int g = 0; g < KF / 16; ++g) {
+      fw[g] = *reinterpret_cast<const f32x4*>(stg + (G::M_PAD + 16 * wn) * ROWB + frag[g]);
+#pragma unroll
+      for (int i = 0; i < G::MTW; ++i) {
+        const int t = wm + G::WPN * i < G::MT ? wm + G::WPN * i : G::MT - 1;
+        fa[g][i] = *reinterpret_cast<const f32x4*>(stg + 16 * t * ROWB + frag[g]);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < KF / 16; ++g)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < G::MTW; ++i) acc[i] = mfma16(fw[g][s], fa[g][i][s], acc[i]);
+  }
+  __syncthreads();
+
+  // ---- epilogue 1: + b1 (+ the upsampled addend), LeakyReLU -> E[pixel][BN]; rows outside the frame are zero ----
+  float* sE = reinterpret_cast<float*>(ring);
+  {
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(b1 + n0 + 16 * wn + 4 * q);
+#pragma unroll
+    for (int i = 0; i < G::MTW; ++i) {
+      const int t = wm + G::WPN * i;
+      if (t < G::MT) {
+        const int px = 16 * t + l15;
+        const int yl = px / HW, x = px - yl * HW, y = y0 + yl;
+        const bool inside = px < G::M && y >= 0 && y < HW;
+        f32x4 v = acc[i] + bias;
+        if (ups && inside) {
+          constexpr int HL = HW / 2;
+          const UpsTap ty = ups_tap((float)(HL - 1) / (float)(HW - 1), y, HL), tx = ups_tap((float)(HL - 1) / (float)(HW - 1), x, HL);
+          const float* g = ups + (size_t)fr * HL * HL * ld_ups + n0 + 16 * wn + 4 * q;
+          v += ups_lerp(ty, tx, *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i0 * HL + tx.i0) * ld_ups),
+                        *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i0 * HL + tx.i1) * ld_ups),
+                        *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i1 * HL + tx.i0) * ld_ups),
+                        *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i1 * HL + tx.i1) * ld_ups));
+        }
+        *reinterpret_cast<f32x4*>(sE + px * BN + (((4 * wn + q) ^ (px & 7)) << 2)) = inside ? lrelu4(v) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue 2: depthwise 3x3 over the strip, + bd, LeakyReLU -> D ----
+  {
+    const int cq = tid % G::NQ, p_first = tid / G::NQ;
+    const float* wq = wd + n0 + 4 * cq;
+    f32x4 wt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(wq + (size_t)t * N);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bd + n0 + 4 * cq);
+    const int oy_first = st * SR, rows_out = G::HO - oy_first < SR ? G::HO - oy_first : SR;
+    float* dq = D + ((size_t)fr * G::HO + oy_first) * G::HO * ldd + n0 + 4 * cq;
+    const int total = rows_out * G::HO;
+    for (int po = p_first; po < total; po += G::PSTEP) {
+      const int oyl = po / G::HO, ox = po - oyl * G::HO;
+      const int iy0 = oyl * STRIDE, ix0 = ox * STRIDE - 1;       // strip-local input row of the first tap: always inside
+      f32x4 a = bv;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = ix0 + kx;
+          if (ix < 0 || ix >= HW) continue;
+          const int px = (iy0 + ky) * HW + ix;
+          a += *reinterpret_cast<const f32x4*>(sE + px * BN + ((cq ^ (px & 7)) << 2)) * wt[ky * 3 + kx];
+        }
+      }
+      *reinterpret_cast<f32x4*>(dq + (size_t)po * ldd) = lrelu4(a);
+    }
+  }
+}
+
+template <int HW, int SR, int STRIDE, int BN, int KF>
+int launch_fs(const float* a, int lda, const float* w1, const float* b1, const float* wd, const float* bd, float* d, int ldd,
+              int frames, int k, int n, const float* ups, int ld_ups, hipStream_t stream) {
+  using G = FSGeom<HW, SR, STRIDE, BN, KF>;
+  auto kern = pw_dw_strip_kernel<HW, SR, STRIDE, BN, KF>;
+  static unsigned long long attr_once = 0;
+  if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)G::lds)) return st;
+  const int n_nt = n / BN;
+  const long long nwg = (long long)frames * G::NS * n_nt;
+  const unsigned long long ab = ((unsigned long long)((long long)frames * G::P - 1) * lda + k) * 4, wb = (unsigned long long)n * k * 4;
+  CASYNC_REQUIRE(nwg < (1ll << 31) && ab < (1ull << 31) && wb < (1ull << 31), "pw_dw: operand larger than 2 GiB");
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), G::lds, stream, a, lda, w1, b1, wd, bd, d, ldd, frames, k, n, n_nt,
+                     (int)nwg, (unsigned)ab, (unsigned)wb, ups, ld_ups);
+  CASYNC_CHECK_HIP(hipGetLastError());
+  return CASYNC_OK;
+}
+
 template <int HW, int F, int BN, int KF>
 int launch_ft(const float* a, int lda, const float* w1, const float* b1, const float* wd, const float* bd, float* d, int ldd,
               int frames, int k, int n, int stride, const float* ups, int ld_ups, hipStream_t stream) {
@@ -232,14 +410,15 @@ int launch_ft(const float* a, int lda, const float* w1, const float* b1, const f
 bool pw_dw_supported(int hw, int cin, int cexp, int stride) {
   if (cin % 16 || cexp % 32) return false;
   if (hw == 10 || hw == 16) return stride == 1;
-  return hw == 20 && (stride == 1 || stride == 2);
+  return (hw == 20 || hw == 40) && (stride == 1 || stride == 2);
 }
 
-const char* pw_dw_kernel_name(int hw, int cexp, int frames) {
+const char* pw_dw_kernel_name(int hw, int cexp, int frames, int stride) {
   static thread_local char buf[64];
   (void)cexp;
   (void)frames;
-  snprintf(buf, sizeof(buf), "pw_dw_kernel<%d, %d, 32, 16>", hw, hw == 10 ? 2 : 1);
+  if (hw == 40) snprintf(buf, sizeof(buf), "pw_dw_strip_kernel<40, %d, %d, 32, 16>", stride == 1 ? 8 : 4, stride);
+  else snprintf(buf, sizeof(buf), "pw_dw_kernel<%d, %d, 32, 16>", hw, hw == 10 ? 2 : 1);
   return buf;
 }
 
@@ -258,6 +437,9 @@ int launch_pw_dw(const void* a, int lda, const void* w1, const float* b1, const 
   const float* wf = static_cast<const float*>(w1);
   float* df = static_cast<float*>(d);
   // 32-channel tiles, 64-B k-tile rows: 31 KB (10x10 frame pairs), 37 KB (16x16), 55 KB (20x20) of LDS per workgroup
+  if (hw == 40)   // strips of 8 (stride 2: 4) output rows: 57 KB of LDS (10 / 5 rows: 65 KB, measured equal)
+    return stride == 1 ? launch_fs<40, 8, 1, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream)
+                       : launch_fs<40, 4, 2, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);
   if (hw == 10) return launch_ft<10, 2, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, uf, ld_ups, stream);
   if (hw == 16) return launch_ft<16, 1, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, uf, ld_ups, stream);
   return launch_ft<20, 1, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, uf, ld_ups, stream);

@@ -36,6 +36,8 @@ MIN_WAVES = {
     "ir_fused_bf16_kernel<32, 64, 32, 1, false>": 5,
     "pw_dw_kernel<10, 2, 32, 16>": 8,
     "pw_dw_kernel<20, 1, 32, 16>": 5,
+    "pw_dw_strip_kernel<40, 8, 1, 32, 16>": 5,
+    "pw_dw_strip_kernel<40, 4, 2, 32, 16>": 5,
     "inc_kernel<float>": 4,
     "outc_kernel<float>": 4,
 }

@@ -397,7 +397,8 @@ def test_ir_fused_with_commuted_upsample(lib, recipe_sd, prefix, cin, h, w, b):
 
 @pytest.mark.parametrize("hw,stride,cin,cexp,frames", [
     (10, 1, 512, 1024, 5), (10, 1, 1024, 2048, 2), (10, 1, 256, 512, 33), (16, 1, 256, 512, 3), (20, 1, 256, 512, 2),
-    (20, 2, 256, 512, 3), (20, 1, 128, 256, 2), (10, 1, 64, 128, 1)])
+    (20, 2, 256, 512, 3), (20, 1, 128, 256, 2), (10, 1, 64, 128, 1),
+    (40, 1, 128, 256, 3), (40, 2, 128, 256, 2), (40, 1, 16, 32, 1), (40, 2, 64, 128, 17)])
 def test_pw_dw_fused(lib, hw, stride, cin, cexp, frames):
     """Expand 1x1 + LeakyReLU + depthwise 3x3 + LeakyReLU in one kernel (pw_dw.hip) vs plain PyTorch: odd frame
     counts (a half-empty frame pair), both channel-tile widths, stride 2, strided operands."""
@@ -425,7 +426,8 @@ def test_pw_dw_fused(lib, hw, stride, cin, cexp, frames):
 
 
 @pytest.mark.parametrize("hw,c_lo,cexp,frames,fused", [(20, 256, 1024, 3, True), (20, 256, 1024, 17, True), (40, 128, 512, 2, False),
-                                                   (20, 64, 256, 2, False), (16, 32, 128, 1, True)])
+                                                   (20, 64, 256, 2, False), (16, 32, 128, 1, True), (40, 128, 512, 3, True),
+                                                   (40, 32, 64, 1, True)])
 def test_up_block_expand_with_commuted_upsample(lib, hw, c_lo, cexp, frames, fused):
     """An Up block's expand conv with the bilinear upsample commuted behind it (module/unet.py:90-96 + 17-20):
     lrelu(W1 . cat(up(lo), skip) + b) == lrelu(up(W1a . lo) + W1b . skip + b).  `G = W1a . lo` runs at the low resolution
