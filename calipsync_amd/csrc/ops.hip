@@ -329,18 +329,17 @@ __global__ __launch_bounds__(256) void inc_kernel(const float* __restrict__ x,
                                                   T* __restrict__ out, int ldc) {
   __shared__ float E[INC_CEXP][INC_HALO + 4];
   __shared__ float O[256][INC_COUT + 1];
-  __shared__ float Wl[620];
+  // the 620 weights are read with uniform addresses straight from memory: scalar loads into SGPRs that the FMAs take
+  // as operands -- staged in LDS they cost ~500 (broadcast) LDS reads per pixel, as many as the kernel has FMAs
   const int tid = threadIdx.x;
-  for (int i = tid; i < 620; i += 256) Wl[i] = packed[i];
-  const float* w1 = Wl;
-  const float* b1 = Wl + 72;
-  const float* wd = Wl + 84;
-  const float* bd = Wl + 192;
-  const float* w2 = Wl + 204;
-  const float* b2 = Wl + 588;
+  const float* w1 = packed;
+  const float* b1 = packed + 72;
+  const float* wd = packed + 84;
+  const float* bd = packed + 192;
+  const float* w2 = packed + 204;
+  const float* b2 = packed + 588;
   const int b = blockIdx.z, ty0 = blockIdx.y * INC_TH, tx0 = blockIdx.x * INC_TW;
   const float* xb = x + (size_t)b * INC_CIN * INC_HW * INC_HW;
-  __syncthreads();
   for (int p = tid; p < INC_HALO; p += 256) {
     const int hy = p / INC_HALO_W, hx = p - hy * INC_HALO_W;
     const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
