@@ -91,6 +91,8 @@ struct CasyncOptions {
                              //   the fused kernel (up3.0 / up4.0); 0 = upsample first, as the reference writes it
   int fuse_dw = 2;           // CASYNC_FUSE_DW: expand GEMM + depthwise 3x3 in one kernel (pw_dw.hip), fp32: 1 = the 10x10 / 16x16 /
                              //   20x20 blocks (whole-frame tiles), 2 = also the 40x40 blocks (row strips)
+  int fuse_dw_min40 = 8;     // CASYNC_FUSE_DW_MIN40: frames per launch from which the 40x40 strips are used (5 strips per frame:
+                             //   B=8 1.312 -> 1.296 ms, B=1 0.841 -> 0.848 ms)
   int ir_stream = 0;         // CASYNC_IR_STREAM: row-streaming fused block (ir_stream.hip; experimental builds only): 1 = where
                              //   it beats the tile kernel in isolation, 2 = every shape it has an instance for
   int ir_stream_min = 2;     // CASYNC_IR_STREAM_MIN: fewest steps per workgroup run of the streaming kernel

@@ -35,6 +35,7 @@ const OptField kFields[] = {
     {"fuse_q", &CasyncOptions::fuse_q},
     {"ups_commute", &CasyncOptions::ups_commute},
     {"fuse_dw", &CasyncOptions::fuse_dw},
+    {"fuse_dw_min40", &CasyncOptions::fuse_dw_min40},
     {"ir_stream", &CasyncOptions::ir_stream},
     {"ir_stream_min", &CasyncOptions::ir_stream_min},
     {"ir_stream_stagger", &CasyncOptions::ir_stream_stagger},
