@@ -256,15 +256,16 @@ def test_full_size_batch_properties(recipe_sd, precision):
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_full_size_batch_against_oracle(recipe_sd, precision):
     """BASELINE configs[2] (and the configs[3] per-GPU shard): 512 DISTINCT frames in one forward; the first and last
-    frame of both lanes (0, 255, 256, 511) against the CPU oracle on exactly those frames.  fp32: the same bars as
-    every other size (north star 1e-3, regression bar 5e-5); bf16: the max / mean bars of the B=2 golden test."""
+    frame of both lanes and frames inside them (0, 1, 127, 255, 256, 300, 510, 511) against the CPU oracle on exactly
+    those frames.  fp32: the same bars as every other size (north star 1e-3, regression bar 5e-5); bf16: the max / mean
+    bars of the B=2 golden test."""
     from oracle import unet_oracle
     m = Model(6, "hubert", precision=precision).to("cuda:0")
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe_sd.items()})
     x, a = recipe.make_inputs_range(0, 512)
     out = m(torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda())
     assert out.shape == (512, 3, 160, 160) and torch.isfinite(out).all()
-    pick = [0, 255, 256, 511]
+    pick = [0, 1, 127, 255, 256, 300, 510, 511]
     torch.set_num_threads(16)
     ref = unet_oracle.forward(unet_oracle.to_torch(recipe_sd), torch.from_numpy(x[pick]), torch.from_numpy(a[pick]))
     d = (out[pick].cpu() - ref).abs()
