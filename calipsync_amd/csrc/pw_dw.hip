@@ -64,6 +64,60 @@ __device__ __forceinline__ int ft_key(int r) {
   else return (0x1320 >> (4 * ((r >> 2) & 3))) & 3;      // {0, 2, 3, 1}
 }
 
+// The GEMM part both kernels share: acc[i] (i-th pixel tile of this wave) = W1 tile x A rows over the whole K, k-tiles
+// arriving by LDS-DMA into a two-stage ring.  voff[j]: this lane's source offset of the wave's j-th LDS-DMA instruction
+// (rows [0, M_PAD) of a stage are A rows, then BN rows of W1); ends with the ring consumed (barrier).
+template <class G, int BN, int KF>
+__device__ __forceinline__ void pw_dw_gemm(char* ring, const float* __restrict__ A, const float* __restrict__ W1, unsigned a_bytes,
+                                           unsigned w_bytes, const int (&voff)[G::LPT], int nk, int wave, int l15, int q,
+                                           f32x4 (&acc)[G::MTW]) {
+  constexpr int ROWB = G::ROWB, RPI = G::RPI;
+  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < G::LPT; ++j) {
+      char* dst = ring + stage * G::STAGE + (j * 4 + wave) * RPI * ROWB;
+      if ((j * 4 + wave) * RPI < G::M_PAD) ft_dma16(A, a_bytes, dst, voff[j], kt * ROWB);
+      else ft_dma16(W1, w_bytes, dst, voff[j], kt * ROWB);
+    }
+  };
+  // wave -> channel tile `wn` and the pixel tiles wm, wm + WPN, ...
+  const int wn = wave % G::NT, wm = wave / G::NT;
+  const int key = ft_key<KF>(l15);                        // key of every fragment row 16 t + l15 (16 t adds nothing)
+  int frag[KF / 16];                                      // this lane's 16 B of each 16-float k-group of a row
+#pragma unroll
+  for (int g = 0; g < KF / 16; ++g) frag[g] = l15 * ROWB + (((4 * g + q) ^ key) << 4);
+#pragma unroll
+  for (int i = 0; i < G::MTW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of k-tile kt has landed
+    __syncthreads();                                   // ... everyone's; and everyone is done reading the other stage
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    const char* st = ring + (kt & 1) * G::STAGE;
+    // all fragments of the k-tile are requested up front, then the MFMAs run back to back: s outer, tile inner, so an
+    // accumulator is reused only every MTW instructions (no dependent-issue stalls)
+    f32x4 fw[KF / 16], fa[KF / 16][G::MTW];
+#pragma unroll
+    for (int g = 0; g < KF / 16; ++g) {
+      fw[g] = *reinterpret_cast<const f32x4*>(st + (G::M_PAD + 16 * wn) * ROWB + frag[g]);
+#pragma unroll
+      for (int i = 0; i < G::MTW; ++i) {
+        // a tile index past the end (BN = 32, second wave of the pair) recomputes the last tile and never stores it
+        const int t = wm + G::WPN * i < G::MT ? wm + G::WPN * i : G::MT - 1;
+        fa[g][i] = *reinterpret_cast<const f32x4*>(st + 16 * t * ROWB + frag[g]);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < KF / 16; ++g)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < G::MTW; ++i) acc[i] = mfma16(fw[g][s], fa[g][i][s], acc[i]);
+  }
+  __syncthreads();   // the ring is consumed: it becomes the E tile
+}
+
 template <int HW, int F, int BN, int KF>
 __global__ __launch_bounds__(256, (FTGeom<HW, F, BN, KF>::occ)) void pw_dw_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W1, const float* __restrict__ b1,
@@ -103,52 +157,9 @@ __global__ __launch_bounds__(256, (FTGeom<HW, F, BN, KF>::occ)) void pw_dw_kerne
       voff[j] = (n0 + wr) * K * 4 + cs * 16;
     }
   }
-  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < G::LPT; ++j) {
-      char* dst = ring + stage * G::STAGE + (j * 4 + wave) * RPI * ROWB;
-      if ((j * 4 + wave) * RPI < G::M_PAD) ft_dma16(A, a_bytes, dst, voff[j], kt * ROWB);
-      else ft_dma16(W1, w_bytes, dst, voff[j], kt * ROWB);
-    }
-  };
-
-  // ---- MFMA: wave -> channel tile `wn` and the pixel tiles wm, wm + WPN, ... ----
   const int wn = wave % G::NT, wm = wave / G::NT;
-  const int key = ft_key<KF>(l15);                        // key of every fragment row 16 t + l15 (16 t adds nothing)
-  int frag[KF / 16];                                      // this lane's 16 B of each 16-float k-group of a row
-#pragma unroll
-  for (int g = 0; g < KF / 16; ++g) frag[g] = l15 * ROWB + (((4 * g + q) ^ key) << 4);
   f32x4 acc[G::MTW];
-#pragma unroll
-  for (int i = 0; i < G::MTW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  issue(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of k-tile kt has landed
-    __syncthreads();                                   // ... everyone's; and everyone is done reading the other stage
-    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-    const char* st = ring + (kt & 1) * G::STAGE;
-    // all fragments of the k-tile are requested up front, then the MFMAs run back to back: s outer, tile inner, so an
-    // accumulator is reused only every MTW instructions (no dependent-issue stalls)
-    f32x4 fw[KF / 16], fa[KF / 16][G::MTW];
-#pragma unroll
-    for (int g = 0; g < KF / 16; ++g) {
-      fw[g] = *reinterpret_cast<const f32x4*>(st + (G::M_PAD + 16 * wn) * ROWB + frag[g]);
-#pragma unroll
-      for (int i = 0; i < G::MTW; ++i) {
-        // a tile index past the end (BN = 32, second wave of the pair) recomputes the last tile and never stores it
-        const int t = wm + G::WPN * i < G::MT ? wm + G::WPN * i : G::MT - 1;
-        fa[g][i] = *reinterpret_cast<const f32x4*>(st + 16 * t * ROWB + frag[g]);
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < KF / 16; ++g)
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < G::MTW; ++i) acc[i] = mfma16(fw[g][s], fa[g][i][s], acc[i]);
-  }
-  __syncthreads();   // the ring is consumed: it becomes the E tile
+  pw_dw_gemm<G, BN, KF>(ring, A, W1, a_bytes, w_bytes, voff, nk, wave, l15, q, acc);
 
   // ---- epilogue 1: + b1, LeakyReLU -> E[pixel][BN] (16-B column XOR pixel & 7) ----
   float* sE = reinterpret_cast<float*>(ring);
@@ -271,48 +282,9 @@ __global__ __launch_bounds__(256, (FSGeom<HW, SR, STRIDE, BN, KF>::occ)) void pw
       voff[j] = (n0 + wr) * K * 4 + cs * 16;
     }
   }
-  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < G::LPT; ++j) {
-      char* dst = ring + stage * G::STAGE + (j * 4 + wave) * RPI * ROWB;
-      if ((j * 4 + wave) * RPI < G::M_PAD) ft_dma16(A, a_bytes, dst, voff[j], kt * ROWB);
-      else ft_dma16(W1, w_bytes, dst, voff[j], kt * ROWB);
-    }
-  };
-
   const int wn = wave % G::NT, wm = wave / G::NT;
-  const int key = ft_key<KF>(l15);
-  int frag[KF / 16];
-#pragma unroll
-  for (int g = 0; g < KF / 16; ++g) frag[g] = l15 * ROWB + (((4 * g + q) ^ key) << 4);
   f32x4 acc[G::MTW];
-#pragma unroll
-  for (int i = 0; i < G::MTW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  issue(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-    const char* stg = ring + (kt & 1) * G::STAGE;
-    f32x4 fw[KF / 16], fa[KF / 16][G::MTW];
-#pragma unroll
-    for (int g = 0; g < KF / 16; ++g) {
-      fw[g] = *reinterpret_cast<const f32x4*>(stg + (G::M_PAD + 16 * wn) * ROWB + frag[g]);
-#pragma unroll
-      for (int i = 0; i < G::MTW; ++i) {
-        const int t = wm + G::WPN * i < G::MT ? wm + G::WPN * i : G::MT - 1;
-        fa[g][i] = *reinterpret_cast<const f32x4*>(stg + 16 * t * ROWB + frag[g]);
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < KF / 16; ++g)
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < G::MTW; ++i) acc[i] = mfma16(fw[g][s], fa[g][i][s], acc[i]);
-  }
-  __syncthreads();
+  pw_dw_gemm<G, BN, KF>(ring, A, W1, a_bytes, w_bytes, voff, nk, wave, l15, q, acc);
 
   // ---- epilogue 1: + b1 (+ the upsampled addend), LeakyReLU -> E[pixel][BN]; rows outside the frame are zero ----
   float* sE = reinterpret_cast<float*>(ring);
