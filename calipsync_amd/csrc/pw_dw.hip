@@ -64,6 +64,18 @@ __device__ __forceinline__ int ft_key(int r) {
   else return (0x1320 >> (4 * ((r >> 2) & 3))) & 3;      // {0, 2, 3, 1}
 }
 
+// four channels of the bilinear x2 upsample (align_corners=True) of a low-resolution tensor g [HL x HL pixels][ld] at
+// high-resolution pixel (y, x): the addend of an Up block's commuted expand conv (common.h GemmEpilogue::ups_src)
+template <int HW>
+__device__ __forceinline__ f32x4 ups_at(const float* g, int ld, int y, int x) {
+  constexpr int HL = HW / 2;
+  const UpsTap ty = ups_tap((float)(HL - 1) / (float)(HW - 1), y, HL), tx = ups_tap((float)(HL - 1) / (float)(HW - 1), x, HL);
+  return ups_lerp(ty, tx, *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i0 * HL + tx.i0) * ld),
+                  *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i0 * HL + tx.i1) * ld),
+                  *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i1 * HL + tx.i0) * ld),
+                  *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i1 * HL + tx.i1) * ld));
+}
+
 // The GEMM part both kernels share: acc[i] (i-th pixel tile of this wave) = W1 tile x A rows over the whole K, k-tiles
 // arriving by LDS-DMA into a two-stage ring.  voff[j]: this lane's source offset of the wave's j-th LDS-DMA instruction
 // (rows [0, M_PAD) of a stage are A rows, then BN rows of W1); ends with the ring consumed (barrier).
@@ -174,14 +186,8 @@ __global__ __launch_bounds__(256, (FTGeom<HW, F, BN, KF>::occ)) void pw_dw_kerne
         if (ups && px < m_valid) {
           // + the bilinear x2 upsample of the low-resolution half of an Up block's expand conv (it commutes with the
           // 1x1 conv: common.h GemmEpilogue::ups_src), HW/2 x HW/2 frames of ld_ups channels
-          constexpr int HL = HW / 2;
           const int f = px / G::P, rem = px - f * G::P, y = rem / HW, x = rem - y * HW;
-          const UpsTap ty = ups_tap((float)(HL - 1) / (float)(HW - 1), y, HL), tx = ups_tap((float)(HL - 1) / (float)(HW - 1), x, HL);
-          const float* g = ups + (size_t)(f0 + f) * HL * HL * ld_ups + n0 + 16 * wn + 4 * q;
-          v += ups_lerp(ty, tx, *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i0 * HL + tx.i0) * ld_ups),
-                        *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i0 * HL + tx.i1) * ld_ups),
-                        *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i1 * HL + tx.i0) * ld_ups),
-                        *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i1 * HL + tx.i1) * ld_ups));
+          v += ups_at<HW>(ups + (size_t)(f0 + f) * (HW / 2) * (HW / 2) * ld_ups + n0 + 16 * wn + 4 * q, ld_ups, y, x);
         }
         *reinterpret_cast<f32x4*>(sE + px * BN + (((4 * wn + q) ^ (px & 7)) << 2)) = lrelu4(v);
       }
@@ -299,13 +305,7 @@ __global__ __launch_bounds__(256, (FSGeom<HW, SR, STRIDE, BN, KF>::occ)) void pw
         const bool inside = px < G::M && y >= 0 && y < HW;
         f32x4 v = acc[i] + bias;
         if (ups && inside) {
-          constexpr int HL = HW / 2;
-          const UpsTap ty = ups_tap((float)(HL - 1) / (float)(HW - 1), y, HL), tx = ups_tap((float)(HL - 1) / (float)(HW - 1), x, HL);
-          const float* g = ups + (size_t)fr * HL * HL * ld_ups + n0 + 16 * wn + 4 * q;
-          v += ups_lerp(ty, tx, *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i0 * HL + tx.i0) * ld_ups),
-                        *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i0 * HL + tx.i1) * ld_ups),
-                        *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i1 * HL + tx.i0) * ld_ups),
-                        *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i1 * HL + tx.i1) * ld_ups));
+          v += ups_at<HW>(ups + (size_t)fr * (HW / 2) * (HW / 2) * ld_ups + n0 + 16 * wn + 4 * q, ld_ups, y, x);
         }
         *reinterpret_cast<f32x4*>(sE + px * BN + (((4 * wn + q) ^ (px & 7)) << 2)) = inside ? lrelu4(v) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
