@@ -81,7 +81,7 @@ struct CasyncOptions {
   int gemm_persist = 1;      // CASYNC_GEMM_PERSIST: persistent grid of the register-staged GEMM
   int lane_streamk = 0;      // CASYNC_LANE_STREAMK: stream-K also when two or more lanes run side by side (the other lane fills tails otherwise)
   int gemm_conc = 3;         // CASYNC_GEMM_CONC: tile policy when lanes share the chip
-  int gemm_conc_tiles = 2048;  // CASYNC_GEMM_CONC_TILES
+  int gemm_conc_tiles = 8192;  // CASYNC_GEMM_CONC_TILES (2048 until the low-resolution W1a GEMMs of the Up blocks: +0.3 % with them on 64x64)
   int fuse_ir = 1;           // CASYNC_FUSE_IR: fused inverted-residual kernel
   int fuse_up = 1;           // CASYNC_FUSE_UP: bilinear upsample folded into up3/up4
   int fuse_min_hw = 32;      // CASYNC_FUSE_MIN_HW: lowest resolution the fused kernel is used at
