@@ -982,7 +982,10 @@ int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullp
   // a little higher here so that it is only chosen where it clearly wins).
   if (casync_opts().gemm_arow && forced < 0 && takes_arow(m, n, k, dtype)) return CAROW;
   if (casync_opts().gemm_wide && forced < 0 && takes_wide(m, n, k, dtype)) return C256x128;
-  const int conc_mode = casync_opts().gemm_conc, conc_tiles = casync_opts().gemm_conc_tiles;
+  // bf16 tiles are bound by data movement, not by the MFMAs: above 2048 tiles the 128-wide tiles win there whatever the
+  // option says (B=512: 33.7 k frames/s against 32.3 k with 64x64 tiles up to 8192)
+  const int conc_mode = casync_opts().gemm_conc;
+  const int conc_tiles = dtype == DT_BF16 && casync_opts().gemm_conc_tiles > 2048 ? 2048 : casync_opts().gemm_conc_tiles;
   const long long t64 = (long long)((m + 63) / 64) * (n / 64);
   int best = -1;
   double best_cost = 0;
