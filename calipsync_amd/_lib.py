@@ -17,13 +17,12 @@ c_i64 = C.c_int64
 
 
 class KernelTime(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("kernel", C.c_char * 64), ("ms", C.c_float), ("flops", C.c_double),
+    _fields_ = [("name", C.c_char * 48), ("kernel", C.c_char * 64), ("ms", C.c_float), ("ms_raw", C.c_float), ("flops", C.c_double),
                 ("bytes", C.c_double)]
 
 
 _PROTOS = {
     "casync_abi_version": (C.c_int, []),
-    "casync_build_flags": (C.c_int, []),
     "casync_last_error": (C.c_char_p, []),
     "casync_packed_count": (C.c_int, []),
     "casync_packed_name": (C.c_char_p, [C.c_int]),
@@ -68,8 +67,6 @@ _PROTOS = {
     "casync_op_ir_fused_upg": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                          c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p]),
-    "casync_op_im2col3x3": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                      C.c_int, C.c_void_p]),
     "casync_op_upsample2x": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p]),
     "casync_op_cross_attention": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int,
@@ -89,7 +86,7 @@ _PROTOS = {
 }
 
 EXPORTS = tuple(_PROTOS)
-ABI_VERSION = 3          # == CASYNC_ABI_VERSION of include/casync_hip.h this file was written against
+ABI_VERSION = 4          # == CASYNC_ABI_VERSION of include/casync_hip.h this file was written against
 
 
 def lib_path() -> str:
@@ -130,11 +127,6 @@ def load() -> C.CDLL:
                            "(python -c 'import __graft_entry__ as g; g.build()')")
     _lib = lib
     return lib
-
-
-def experimental() -> bool:
-    """True when the loaded library was built with CASYNC_EXPERIMENTAL=1 (kernels measured and not adopted)."""
-    return bool(load().casync_build_flags() & 1)
 
 
 def set_option(name: str, value: int, handle=None) -> None:

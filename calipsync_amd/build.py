@@ -12,15 +12,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libcasync_hip.so")
-SOURCES = ["runtime.hip", "gemm.hip", "ops.hip", "ir_fused.hip", "ir_stream.hip", "pw_dw.hip", "attention.hip", "frame_ops.hip", "engine.hip"]
-HEADERS = ["common.h", "ir_common.h", "gemm_experimental.inc", os.path.join("..", "..", "include", "casync_hip.h")]
+SOURCES = ["runtime.hip", "gemm.hip", "ops.hip", "ir_fused.hip", "pw_dw.hip", "attention.hip", "frame_ops.hip", "engine.hip"]
+HEADERS = ["common.h", "ir_common.h", os.path.join("..", "..", "include", "casync_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
-# CASYNC_EXPERIMENTAL=1: also compile the kernels that were measured and not adopted (gemm_experimental.inc, deeper GEMM
-# rings, extra tile shapes, im2col).  The product library is built without them; a switch between the two rebuilds.
-EXPERIMENTAL = os.environ.get("CASYNC_EXPERIMENTAL", "0") not in ("", "0")
-if EXPERIMENTAL:
-    FLAGS.append("-DCASYNC_EXPERIMENTAL=1")
-FLAVOUR_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", ".flavour")
 
 
 def _hipcc() -> str:
@@ -44,21 +38,7 @@ def _header_paths():
 def is_stale() -> bool:
     """True when the library is missing or older than any of its sources / headers.  A deployment that ships the
     library without csrc/ has nothing to be stale against: missing sources count as "not newer"."""
-    return _flavour_changed() or _newer(LIB_PATH, [os.path.join(CSRC, s) for s in SOURCES] + _header_paths())
-
-
-def _flavour() -> str:
-    return "experimental" if EXPERIMENTAL else "product"
-
-
-def _flavour_changed() -> bool:
-    """The objects on disk were compiled for the other flavour (with / without CASYNC_EXPERIMENTAL)."""
-    if not os.path.exists(LIB_PATH):
-        return False
-    try:
-        return open(FLAVOUR_FILE).read().strip() != _flavour()
-    except OSError:
-        return EXPERIMENTAL     # no record: a library without one is a product build
+    return _newer(LIB_PATH, [os.path.join(CSRC, s) for s in SOURCES] + _header_paths())
 
 
 def source_hash() -> str:
@@ -96,7 +76,6 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 def _build_locked(force: bool, verbose: bool) -> str:
     hipcc = _hipcc()
-    force = force or _flavour_changed()
 
     def compile_one(src: str):
         obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
@@ -124,8 +103,6 @@ def _build_locked(force: bool, verbose: bool) -> str:
             os.remove(tmp)
         raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(tmp, LIB_PATH)
-    with open(FLAVOUR_FILE, "w") as f:
-        f.write(_flavour() + "\n")
     return LIB_PATH
 
 

@@ -38,7 +38,7 @@ __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : v * CASYN
 // Bilinear x2 upsample with align_corners=True (module/unet.py:86-91), the arithmetic of ATen's upsample_bilinear2d
 // evaluated exactly as written: src = dst * (in-1)/(out-1), l1 = frac, l0 = 1 - l1, taps combined as
 // l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11).  No fma contraction, so every kernel that folds the upsample
-// (upsample2x_kernel, ir_fused, ir_stream) produces the SAME bits -- what the compiler fuses would otherwise differ
+// (upsample2x_kernel, ir_fused) produces the SAME bits -- what the compiler fuses would otherwise differ
 // from one surrounding code to the next.
 struct UpsTap { int i0, i1; float l0, l1; };
 __device__ __forceinline__ UpsTap ups_tap(float scale, int dst, int n_in) {
@@ -75,9 +75,6 @@ struct CasyncOptions {
   int gemm_streamk = 1;      // CASYNC_GEMM_STREAMK: stream-K remainders in single-lane runs
   int gemm_glds = 2;         // CASYNC_GEMM_GLDS: LDS-DMA ring GEMM: 0 off, 1 bf16 only, 2 both types
   int gemm_cfg = -1;         // CASYNC_GEMM_CFG: force one tile configuration
-  int gemm_pipe = 0;         // CASYNC_GEMM_PIPE: stages of the software-pipelined LDS-DMA ring, 3..6 (0 = the round-1 loop)
-  int gemm_arow = 0;         // CASYNC_GEMM_AROW: A-stationary kernel (A rows in registers, W streamed) for the bf16 plan's K = 256 / 512 GEMMs
-  int gemm_wide = 0;         // CASYNC_GEMM_WIDE: 1 = 256x128 persistent ring kernel for the bf16 plan's large GEMMs (2 = with k-skew); measured equal to the 128x128 kernel, off
   int gemm_persist = 1;      // CASYNC_GEMM_PERSIST: persistent grid of the register-staged GEMM
   int lane_streamk = 0;      // CASYNC_LANE_STREAMK: stream-K also when two or more lanes run side by side (the other lane fills tails otherwise)
   int gemm_conc = 3;         // CASYNC_GEMM_CONC: tile policy when lanes share the chip
@@ -93,16 +90,8 @@ struct CasyncOptions {
                              //   20x20 blocks (whole-frame tiles), 2 = also the 40x40 blocks (row strips)
   int fuse_dw_min40 = 8;     // CASYNC_FUSE_DW_MIN40: frames per launch from which the 40x40 strips are used (5 strips per frame:
                              //   B=8 1.312 -> 1.296 ms, B=1 0.841 -> 0.848 ms)
-  int ir_stream = 0;         // CASYNC_IR_STREAM: row-streaming fused block (ir_stream.hip; experimental builds only): 1 = where
-                             //   it beats the tile kernel in isolation, 2 = every shape it has an instance for
-  int ir_stream_min = 2;     // CASYNC_IR_STREAM_MIN: fewest steps per workgroup run of the streaming kernel
-  int ir_stream_stagger = 0; // CASYNC_IR_STREAM_STAGGER: start delay between the workgroups that share a CU, x64 cycles
-  int ir_stream_skew = 0;    // CASYNC_IR_STREAM_SKEW: start delay per (workgroup % 16), x64 cycles
-  int ir_stream_wgs = 0;     // CASYNC_IR_STREAM_WGS: workgroups per CU of the streaming grid (0 = what fits)
-  int ir_stream_prio = 1;    // CASYNC_IR_STREAM_PRIO: the depthwise (VALU) phase runs at raised wave priority
   int dw_lds = 1;            // CASYNC_DW_LDS: LDS-slab depthwise kernel
   int dw_lds_bytes = 32768;  // CASYNC_DW_LDS_BYTES
-  int conv_im2col = 0;       // CASYNC_CONV_IM2COL: dense 3x3 via im2col + GEMM instead of the implicit GEMM
   int att_nz = 0;            // CASYNC_ATT_NZ: channel split of the attention kernel (0 = by batch)
 };
 CasyncOptions& casync_default_options();      // process defaults (environment read once, thread-safe)
@@ -224,13 +213,6 @@ const char* dw3x3_kernel_name(int h, int wdt, int c, int stride, int dtype = DT_
 bool ir_fused_supported(int cin, int cout, int stride);
 // as rocprofv3 prints it; h, w > 0: the instance launch_ir_fused / launch_ir_fused_up picks for that shape
 const char* ir_fused_kernel_name(int cin, int cout, int stride, int dtype = DT_F32, bool ups = false, int h = 0, int w = 0);
-// row-streaming variant (ir_stream.hip): fp32, stride 1, whole 8 x 16 steps
-unsigned long long* casync_ir_stamps();   // diagnostic stamp buffer of this thread (casync_debug_ir_stamps), or null
-bool ir_stream_supported(int cin, int cout, int stride, int h, int w, bool ups, int res);
-const char* ir_stream_kernel_name(int cin, int cout, int stride, bool ups);
-int launch_ir_stream(const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const void* w1, const float* b1,
-                     const float* wd, const float* bd, const void* w2, const float* b2, void* out, int ld_out,
-                     int batch, int h, int w, int cin, int cout, int stride, int res, bool ups, hipStream_t stream);
 bool ir_fused_up_supported(int cin, int cout);
 int launch_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const void* w1,
                        const float* b1, const float* wd, const float* bd, const void* w2,
@@ -254,8 +236,6 @@ const char* pw_dw_kernel_name(int hw, int cexp, int frames, int stride = 1);
 // activation (an Up block's upsampled half, see GemmEpilogue::ups_src)
 int launch_pw_dw(const void* a, int lda, const void* w1, const float* b1, const float* wd, const float* bd, void* d, int ldd,
                  int frames, int hw, int stride, int cin, int cexp, hipStream_t stream, const void* ups = nullptr, int ld_ups = 0);
-int launch_im2col3x3(const void* in, void* out, int batch, int h, int wdt, int c, int stride,
-                     int pad, hipStream_t stream, int dtype = DT_F32);
 int launch_upsample2x(const void* in, void* out, int ldc, int batch, int h, int wdt, int c,
                       hipStream_t stream, int dtype = DT_F32);
 int launch_cross_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,

@@ -166,6 +166,22 @@ bool ir_is_fused(const CasyncOptions& o, const IR& b) {
 bool up_is_fused(const CasyncOptions& o, const IR& b0) {
   return o.fuse_ir && o.fuse_up && b0.hw_in >= o.fuse_min_hw && ir_fused_up_supported(b0.cin, b0.cout);
 }
+// How the first inverted residual of an Up stage takes its upsampled half.  ONE predicate for the plan (decode()) and for
+// the workspace (max_unfused_expand()): round 3 had them apart and `fuse_up=0` sent up3.0 / up4.0 down the un-fused chain
+// with E1 / E2 sized for up2.0.
+enum class UpMode {
+  CommuteUnfused,   // G = W1a.lo at the low resolution, then the un-fused chain (pw_dw / GEMM + depthwise) adds up(G)
+  CommuteFused,     // G = W1a.lo, then ir_fused_kernel<.., UPS = 2>
+  FusedLoad,        // ir_fused_kernel<.., UPS = 1>: bilinear taps while loading the A fragments
+  Materialise       // upsample2x into the concat buffer, then the block as any other inverted residual
+};
+UpMode up_mode(const CasyncOptions& o, const IR& b0, int dtype) {
+  const bool f32 = dtype == DT_F32;
+  if (up_is_fused(o, b0)) return f32 && o.ups_commute >= 2 ? UpMode::CommuteFused : UpMode::FusedLoad;
+  // a block the plain fused kernel takes (fuse_up = 0, fuse_ir = 1) keeps it: upsample first, E never leaves LDS
+  if (f32 && o.ups_commute && !ir_is_fused(o, b0)) return UpMode::CommuteUnfused;
+  return UpMode::Materialise;
+}
 int64_t max_unfused_expand(const CasyncOptions& o) {
   int64_t mx = 0;
   auto see = [&](const IR& b, bool fused) {
@@ -174,7 +190,7 @@ int64_t max_unfused_expand(const CasyncOptions& o) {
   for (auto& st : kDown)
     for (auto& b : st) see(b, ir_is_fused(o, b));
   for (auto& b : kFuse) see(b, ir_is_fused(o, b));
-  for (auto& st : kUp) {
+  for (auto& st : kUp) {   // (dtype-independent: the fp32-only modes never un-fuse a block bf16 would fuse)
     see(st[0], up_is_fused(o, st[0]) || ir_is_fused(o, st[0]));
     see(st[1], ir_is_fused(o, st[1]));
   }
@@ -191,7 +207,7 @@ struct Arena {
   int esz = 4;
   enum Id {
     CAT4, CAT3, CAT2, CAT1, CATA, E1, E2, T0, U4, F, FM, U1, U2, U3, UG,
-    A0, AC1, AC2, IM, AC3, AC4, AC5, AC6, AE1, AE2,
+    A0, AC1, AC2, AC3, AC4, AC5, AC6, AE1, AE2,
     H, TX, OX0, OX1, OX2, OX3, KX, KXF, P1Q, AO, Q, KV, COUNT
   };
   Buf b[COUNT] = {
@@ -201,7 +217,7 @@ struct Arena {
       {"F", 100 * 256, 0},          {"FM", 100 * 512, 0},        {"U1", 400 * 128, 0},
       {"U2", 1600 * 64, 0},         {"U3", 6400 * 32, 0},        {"UG", 6400 * 128, 0},   // W1a . lo of an Up block, low res
       {"A0", 1024 * 32, 0},
-      {"AC1", 1024 * 64, 0},        {"AC2", 1024 * 128, 0},      {"IM", 256 * 1152, 0},
+      {"AC1", 1024 * 64, 0},        {"AC2", 1024 * 128, 0},
       {"AC3", 256 * 256, 0},        {"AC4", 256 * 256, 0},       {"AC5", 100 * 512, 0},
       {"AC6", 100 * 512, 0},        {"AE1", 131072, 0},          {"AE2", 131072, 0},
       {"H", 100 * 1024, 0},         {"TX", 100 * 1024, 0},       {"OX0", 100 * 1024, 0},
@@ -210,11 +226,6 @@ struct Arena {
       {"AO", 100 * 512, 0},         {"Q", 100 * 64, 0},          {"KV", 100 * kBlocks * kKV, 0}};
   explicit Arena(const CasyncOptions& o) {
     b[E1].per_frame = b[E2].per_frame = max_unfused_expand(o);
-#ifdef CASYNC_EXPERIMENTAL
-    if (!o.conv_im2col) b[IM].per_frame = 0;   // the implicit-GEMM convs need no patch buffer
-#else
-    b[IM].per_frame = 0;
-#endif
   }
   static int64_t bytes(const CasyncOptions& o, int batch, int esz = 4) {
     Arena a(o);
@@ -235,6 +246,12 @@ struct Arena {
     for (auto& x : b) x.p += x.per_frame * (int64_t)b0 * esz;
   }
   Ptr operator[](Id i) const { return Ptr{b[i].p, esz}; }
+  // elements per frame of the buffer that starts at `p` (-1: not the start of a buffer)
+  int64_t per_frame_of(const Ptr& p) const {
+    for (auto& x : b)
+      if (x.p == p.p) return x.per_frame;
+    return -1;
+  }
 };
 
 // hipSetDevice for the life of a scope (the caller's device is restored on exit)
@@ -345,7 +362,8 @@ struct Runner {
     const float overhead = gaps[NCAL / 2];
     for (size_t i = 0; i < rec.size(); ++i) {
       (void)hipEventElapsedTime(&rec[i].ms, ev[2 * i], ev[2 * i + 1]);
-      rec[i].ms = rec[i].ms > overhead ? rec[i].ms - overhead : rec[i].ms;
+      rec[i].ms_raw = rec[i].ms;
+      rec[i].ms = rec[i].ms > overhead ? rec[i].ms - overhead : 0.f;
       (void)hipEventDestroy(ev[2 * i]);
       (void)hipEventDestroy(ev[2 * i + 1]);
     }
@@ -402,22 +420,13 @@ struct Plan {
   }
 
   // Dense 3x3 conv + bias + LReLU (audio conv3 / conv5, module/unet.py:161-168) as an implicit GEMM:
-  // the ring kernel gathers the taps itself (CASYNC_CONV_IM2COL=1 restores im2col + plain GEMM).
+  // the ring kernel gathers the taps itself (no im2col buffer).
   void conv3x3(const std::string& tag, Ptr in, const std::string& wname, Ptr out, int hw, int cin, int cout,
                int stride, int pad) {
     const int ho = (hw + 2 * pad - 3) / stride + 1;
     const long long m = (long long)B * ho * ho;
     GemmEpilogue ep;
     ep.act = 1;
-#ifdef CASYNC_EXPERIMENTAL
-    if (o.conv_im2col) {
-      r.run((tag + ".im2col").c_str(), kname("im2col3x3_kernel").c_str(), 0,
-            dtype_size(dt()) * (double)B * ((double)hw * hw * cin + (double)ho * ho * 9 * cin),
-            [&] { return launch_im2col3x3(in, ar[Arena::IM], B, hw, hw, cin, stride, pad, r.s, dt()); });
-      gemm(tag, ar[Arena::IM], 9 * cin, wname, out, cout, m, cout, 9 * cin, ep);
-      return;
-    }
-#endif
     ep.bias = e.W(wname.substr(0, wname.size() - 1) + "b");
     ep.concurrent = concurrent ? 1 : 0;
     if (char* ctx = stream_k ? e.sk_ctx(lane, aux && r.s == aux ? 1 : 0) : nullptr) {
@@ -450,6 +459,14 @@ struct Plan {
                                e.W(p + ".dw.b"), e.WG(p + ".pw2.w"), e.W(p + ".pw2.b"), out, ld_out, B,
                                b.hw_in, b.hw_in, b.cin, b.cout, b.stride, b.res, r.s, dt());
       });
+      return;
+    }
+    // the un-fused chain parks the expanded tensor in e1 / e2: they must have been sized for this block (the arena's
+    // predicate and the plan's are the same functions; this catches the day they are not)
+    if (ar.per_frame_of(e2) < (int64_t)b.hw_in * b.hw_in * b.cexp()) {
+      casync_set_error("plan: %s un-fused needs %lld expanded elements per frame, the workspace slot holds %lld", b.prefix,
+                       (long long)b.hw_in * b.hw_in * b.cexp(), (long long)ar.per_frame_of(e2));
+      r.status = CASYNC_ERR_STATE;
       return;
     }
     // (from 16 frames per launch: below that its whole-frame tiles are too few to fill the chip -- B=1 0.92 vs 0.82 ms)
@@ -627,15 +644,15 @@ struct Plan {
     for (int i = 0; i < 4; ++i) {
       const int cc = 2 * c;  // concat width
       const IR& b0 = kUp[i][0];
-      const bool commute = o.ups_commute && dt() == DT_F32 && !up_is_fused(o, b0);
-      if (commute) {
+      const UpMode mode = up_mode(o, b0, dt());
+      if (mode == UpMode::CommuteUnfused) {
         // upsample and 1x1 conv commute: the upsampled half of the expand conv runs on the LOW-resolution tensor
         // (a quarter of the pixels: 37.5 % of this GEMM's multiply-adds never happen), the consumer adds its bilinear
         // x2 upsample before the activation.  Every launch books the flops it executes.
         gemm(std::string(b0.prefix) + ".pw1a", lo, c, std::string(b0.prefix) + ".pw1a.w", ar[A::UG], b0.cexp(),
              (long long)B * hw * hw, b0.cexp(), c, GemmEpilogue(), "-", 2.0 * B * hw * hw * (double)c * b0.cexp());
         ir(b0, cat[i] + c, cc, T0, b0.cout, E1, E2, nullptr, ar[A::UG]);
-      } else if (o.ups_commute >= 2 && dt() == DT_F32 && up_is_fused(o, b0)) {
+      } else if (mode == UpMode::CommuteFused) {
         // the same commutation inside the fused kernel: G = W1a * lo by a GEMM at the low resolution, the fused
         // block runs its expand over the skip half only and adds up(G) chunk by chunk from LDS
         const std::string p = b0.prefix;
@@ -650,7 +667,7 @@ struct Plan {
                                            e.W(p + ".pw2.w"), e.W(p + ".pw2.b"), (float*)T0.p, b0.cout, B, 2 * hw,
                                            2 * hw, b0.cin, b0.cout, r.s);
               });
-      } else if (up_is_fused(o, b0)) {
+      } else if (mode == UpMode::FusedLoad) {
         // bilinear x2 folded into the fused block's input load: up(x) is never materialised
         const std::string p = b0.prefix;
         const double m = (double)B * 4 * hw * hw;
@@ -707,13 +724,6 @@ int check_forward_args(casync_handle h, const float* x, const float* a, float* o
 extern "C" {
 
 int casync_abi_version(void) { return CASYNC_ABI_VERSION; }
-int casync_build_flags(void) {
-#ifdef CASYNC_EXPERIMENTAL
-  return CASYNC_BUILD_EXPERIMENTAL;
-#else
-  return 0;
-#endif
-}
 int casync_packed_count(void) { return (int)layout().items.size(); }
 const char* casync_packed_name(int i) {
   return (i >= 0 && i < casync_packed_count()) ? layout().items[i].name.c_str() : nullptr;
@@ -736,16 +746,10 @@ int casync_set_option(casync_handle h, const char* name, int value) {
   int* slot = nullptr;
   const int st = casync_option_ref(h ? h->opt : casync_default_options(), name, &slot);
   if (st != CASYNC_OK) return st;
-#ifndef CASYNC_EXPERIMENTAL
-  // switches of kernels that are not in this build (measured and not adopted: gemm_experimental.inc, ir_stream.hip,
-  // im2col, the deeper rings, the experimental tile shapes) can only be set to "off"
-  const bool exp_switch = !strcmp(name, "gemm_arow") || !strcmp(name, "gemm_wide") || !strcmp(name, "gemm_pipe") ||
-                          !strcmp(name, "conv_im2col") || !strcmp(name, "ir_stream");
-  if ((exp_switch && value != 0) || (!strcmp(name, "gemm_cfg") && value >= 4)) {
-    casync_set_error("option %s=%d needs a library built with CASYNC_EXPERIMENTAL=1", name, value);
-    return CASYNC_ERR_STATE;
+  if (!strcmp(name, "gemm_cfg") && value >= 4) {
+    casync_set_error("option gemm_cfg=%d: tile configurations are 0..3 (-1 = cost model)", value);
+    return CASYNC_ERR_ARG;
   }
-#endif
   *slot = value;
   return CASYNC_OK;
 }
@@ -1162,10 +1166,6 @@ int casync_op_ir_fused_upg(const float* g, int ld_g, const float* in, int ld_in,
                            int batch, int h, int w, int cin, int cout, casync_stream stream) {
   return launch_ir_fused_upg(g, ld_g, in, ld_in, w1b, b1, wd, bd, w2, b2, out, ld_out, batch, h, w, cin, cout,
                              (hipStream_t)stream);
-}
-int casync_op_im2col3x3(const void* in, void* out, int batch, int h, int wdt, int c, int stride,
-                        int pad, casync_stream stream) {
-  return launch_im2col3x3(in, out, batch, h, wdt, c, stride, pad, (hipStream_t)stream, g_op_dtype);
 }
 int casync_op_upsample2x(const void* in, void* out, int ldc, int batch, int h, int wdt, int c,
                          casync_stream stream) {

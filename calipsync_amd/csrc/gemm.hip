@@ -838,9 +838,6 @@ int launch_glds_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, 
   return CASYNC_OK;
 }
 
-#ifdef CASYNC_EXPERIMENTAL
-#include "gemm_experimental.inc"   // pw_gemm_wide_kernel, pw_gemm_arow_kernel (measured, not adopted)
-#endif
 
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, int k,
@@ -879,21 +876,11 @@ int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, i
   // one tile per CU anyway (then its deeper pipeline wins), else the register-staged kernel with
   // two co-resident workgroups.  The smaller tiles always take the ring.
   const long long tiles = (long long)((m + BM - 1) / BM) * (n / BN);
-#ifdef CASYNC_EXPERIMENTAL
-  const int pipe = casync_opts().gemm_pipe;   // software-pipelined ring: number of stages (0 = the default loops)
-#else
-  constexpr int pipe = 0;                     // deeper rings than the default 2 / 3 stages: experimental builds only
-#endif
   const size_t esz = dtype == DT_BF16 ? 2 : 4;
   const bool fits32 = ((size_t)(m - 1) * lda + k) * esz < (1ull << 31) && (size_t)n * k * esz < (1ull << 31);
-  const bool ring_ok = fits32 && (pipe != 0 || (BM + BN) < 256 || tiles <= 256);
+  const bool ring_ok = fits32 && ((BM + BN) < 256 || tiles <= 256);
   if constexpr (WM * WN == 4 && BN >= 64) {
     if (ring_ok && dtype == DT_BF16 && glds_mode() >= 1) {
-#ifdef CASYNC_EXPERIMENTAL
-      if (pipe)
-        return launch_glds_t<bf16_t, BM, BN, WM, WN, 3>(static_cast<const bf16_t*>(a), lda, static_cast<const bf16_t*>(w),
-                                                        static_cast<bf16_t*>(c), ldc, m, n, k, epi, stream, use_sk);
-#endif
       return launch_glds_t<bf16_t, BM, BN, WM, WN, NST2>(static_cast<const bf16_t*>(a), lda, static_cast<const bf16_t*>(w),
                                                          static_cast<bf16_t*>(c), ldc, m, n, k, epi, stream, use_sk);
     }
@@ -901,16 +888,6 @@ int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, i
       const float* af = static_cast<const float*>(a);
       const float* wf = static_cast<const float*>(w);
       float* cf = static_cast<float*>(c);
-#ifdef CASYNC_EXPERIMENTAL
-      constexpr int STAGE_KB = (BM + BN) * ROWB / 1024;
-      if constexpr (4 * STAGE_KB <= 160)
-        if (pipe == 4) return launch_glds_t<float, BM, BN, WM, WN, 4>(af, lda, wf, cf, ldc, m, n, k, epi, stream, use_sk);
-      if constexpr (5 * STAGE_KB <= 160)
-        if (pipe == 5) return launch_glds_t<float, BM, BN, WM, WN, 5>(af, lda, wf, cf, ldc, m, n, k, epi, stream, use_sk);
-      if constexpr (6 * STAGE_KB <= 160)
-        if (pipe == 6) return launch_glds_t<float, BM, BN, WM, WN, 6>(af, lda, wf, cf, ldc, m, n, k, epi, stream, use_sk);
-      if (pipe) return launch_glds_t<float, BM, BN, WM, WN, 3>(af, lda, wf, cf, ldc, m, n, k, epi, stream, use_sk);
-#endif
       return launch_glds_t<float, BM, BN, WM, WN, NST2>(af, lda, wf, cf, ldc, m, n, k, epi, stream, use_sk);
     }
   }
@@ -924,51 +901,23 @@ int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, i
 // Tile choice.  On a 256-CU chip a launch of G workgroups finishes after ceil(G/256) "rounds" of
 // one tile per CU (co-resident tiles share the CU's matrix pipes, so they add, not overlap);
 // pick the tile that minimises rounds x tile area, preferring the larger tile on ties.
-enum Cfg { C128x128 = 0, C128x64, C64x64, C128x32, C64x32, C64x64W2, C256x128, CAROW, CFG_COUNT };
+enum Cfg { C128x128 = 0, C128x64, C64x64, C128x32, CFG_COUNT };
 
 struct TileCfg { Cfg id; int bm, bn; };
-constexpr TileCfg kTiles[] = {{C128x128, 128, 128}, {C128x64, 128, 64}, {C64x64, 64, 64}, {C128x32, 128, 32},
-                              {C64x32, 64, 32}, {C64x64W2, 64, 64}, {C256x128, 256, 128}, {CAROW, 128, 128}};
-
-// the A-stationary kernel (pw_gemm_arow_kernel): bf16, K = 256 / 512, whole 128-row blocks, at least half a chip of them
-bool takes_arow(int m, int n, int k, int dtype) {
-#ifndef CASYNC_EXPERIMENTAL
-  return false;
-#endif
-  return dtype == DT_BF16 && m % 128 == 0 && n % 128 == 0 && (k == 512 || (k == 256 && casync_opts().gemm_arow >= 2)) &&
-         m / 128 >= 128;   // K = 256 leaves two thirds of LDS unused by a lone workgroup per CU and measured equal
-}
-// the wide persistent ring kernel (pw_gemm_wide_kernel): bf16, whole 256x128 tiles, at least one per CU
-bool takes_wide(int m, int n, int k, int dtype) {
-#ifndef CASYNC_EXPERIMENTAL
-  return false;
-#endif
-  return dtype == DT_BF16 && m % 256 == 0 && n % 128 == 0 && k / (ROWB / 2) >= 4 && (long long)(m / 256) * (n / 128) >= 256;
-}
+constexpr TileCfg kTiles[] = {{C128x128, 128, 128}, {C128x64, 128, 64}, {C64x64, 64, 64}, {C128x32, 128, 32}};
 
 // does launch_cfg() send this config to the LDS-DMA ring kernel?
-inline int gemm_pipe_opt() {
-#ifdef CASYNC_EXPERIMENTAL
-  return casync_opts().gemm_pipe;
-#else
-  return 0;
-#endif
-}
 bool takes_ring(const TileCfg& t, long long tiles, int dtype) {
   return (t.id == C128x128 || t.id == C128x64 || t.id == C64x64) &&
-         (gemm_pipe_opt() != 0 || t.bm + t.bn < 256 || tiles <= 256) &&
+         (t.bm + t.bn < 256 || tiles <= 256) &&
          ((dtype == DT_BF16 && glds_mode() >= 1) || (dtype == DT_F32 && glds_mode() >= 2));
 }
 
 int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullptr, bool concurrent = false) {
-  int forced = casync_opts().gemm_cfg;
-#ifndef CASYNC_EXPERIMENTAL
-  if (forced >= C64x32) forced = -1;   // the experimental tile shapes / kernels are not in this build
-#endif
+  const int forced = casync_opts().gemm_cfg;
   const int nk = k / (ROWB / dtype_size(dtype));
   if (use_sk) *use_sk = false;
-  if (forced == CAROW ? (takes_arow(m, n, k, dtype) || (dtype == DT_BF16 && m % 128 == 0 && n % 128 == 0 && k == 256 && m / 128 >= 128))
-                      : forced == C256x128 ? takes_wide(m, n, k, dtype) : forced >= 0 && forced < CFG_COUNT && n % kTiles[forced].bn == 0) {
+  if (forced >= 0 && forced < CFG_COUNT && n % kTiles[forced].bn == 0) {
     const TileCfg& t = kTiles[forced];
     const long long g = (long long)((m + t.bm - 1) / t.bm) * (n / t.bn);
     if (use_sk) *use_sk = takes_ring(t, g, dtype) && stream_k_split(g, nk, t.bm * t.bn, stream_k).wgs > 0;
@@ -980,8 +929,6 @@ int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullp
   // +600 is the worse operand reuse of small tiles.  Stream-K makes the last round fractional
   // and adds ~5 us (64x64) to ~10 us (128x64) of short-run start-up, parking and fix-up (priced
   // a little higher here so that it is only chosen where it clearly wins).
-  if (casync_opts().gemm_arow && forced < 0 && takes_arow(m, n, k, dtype)) return CAROW;
-  if (casync_opts().gemm_wide && forced < 0 && takes_wide(m, n, k, dtype)) return C256x128;
   // bf16 tiles are bound by data movement, not by the MFMAs: above 2048 tiles the 128-wide tiles win there whatever the
   // option says (B=512: 33.7 k frames/s against 32.3 k with 64x64 tiles up to 8192)
   const int conc_mode = casync_opts().gemm_conc;
@@ -990,7 +937,7 @@ int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullp
   int best = -1;
   double best_cost = 0;
   for (const TileCfg& t : kTiles) {
-    if (n % t.bn || t.id >= C64x32) continue;   // experimental configs: only when forced
+    if (n % t.bn) continue;
     if (concurrent && n % 64 == 0) {
       if (conc_mode == 1 && t.id != C64x64) continue;
       if (conc_mode == 2 && t.id == C128x128) continue;
@@ -1027,19 +974,12 @@ const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype, b
     case C128x128: cfg = "128, 128, 2, 2"; break;
     case C128x64: cfg = "128, 64, 2, 2"; break;
     case C64x64: cfg = "64, 64, 2, 2"; break;
-    case C64x32: cfg = "64, 32, 2, 1"; break;
-    case C64x64W2: cfg = "64, 64, 2, 1"; break;
     default: cfg = "128, 32, 4, 1"; break;
   }
   const TileCfg& tc = kTiles[id];
   const long long tiles = (long long)((m + tc.bm - 1) / tc.bm) * (n / tc.bn);
-  if (id == CAROW)
-    snprintf(buf, sizeof(buf), "pw_gemm_arow_kernel<%s, %d>", t, k / 16);
-  else if (id == C256x128)
-    snprintf(buf, sizeof(buf), "pw_gemm_wide_kernel<%s, 256, 128, 4, 2, 3>", t);
-  else if (takes_ring(tc, tiles, dtype))
-    snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, %d, false>", t, cfg,
-             gemm_pipe_opt() != 0 || tc.bm + tc.bn >= 256 ? 3 : 2);
+  if (takes_ring(tc, tiles, dtype))
+    snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, %d, false>", t, cfg, tc.bm + tc.bn >= 256 ? 3 : 2);
   else
     snprintf(buf, sizeof(buf), "pw_gemm_kernel<%s, %s>", t, cfg);
   return buf;
@@ -1077,24 +1017,6 @@ int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int 
     case C128x128: return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
     case C128x64: return launch_cfg<128, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
     case C64x64: return launch_cfg<64, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
-#ifdef CASYNC_EXPERIMENTAL
-    case C64x32: return launch_cfg<64, 32, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
-    case C64x64W2: return launch_cfg<64, 64, 2, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
-    case CAROW:
-      if ((size_t)n * k * 2 < (1ull << 31)) {
-        const bf16_t* ab = static_cast<const bf16_t*>(a);
-        const bf16_t* wbp = static_cast<const bf16_t*>(w);
-        bf16_t* cb = static_cast<bf16_t*>(c);
-        return k == 512 ? launch_arow_t<bf16_t, 32>(ab, lda, wbp, cb, ldc, m, n, epi, stream)
-                        : launch_arow_t<bf16_t, 16>(ab, lda, wbp, cb, ldc, m, n, epi, stream);
-      }
-      return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
-    case C256x128:
-      if (((size_t)(m - 1) * lda + k) * 2 < (1ull << 31) && (size_t)n * k * 2 < (1ull << 31))
-        return launch_wide_t<bf16_t, 256, 128, 4, 2, 3>(static_cast<const bf16_t*>(a), lda, static_cast<const bf16_t*>(w),
-                                                        static_cast<bf16_t*>(c), ldc, m, n, k, epi, stream);
-      return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
-#endif
     default: return launch_cfg<128, 32, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
   }
 }
@@ -1108,11 +1030,6 @@ int launch_conv_t(const T* in, const T* w, T* out, int ldc, int m, int n, int k,
   const int cfg = pick_cfg(m, n, k, epi.sk_ws != nullptr, dtype, &sk, epi.concurrent != 0);
   // the ring kernel's two 48-KB-class tiles; the A "leading dimension" is unused (rows are gathered)
   const bool small = cfg == C64x64 || n % 64 || m <= 4096;
-#ifdef CASYNC_EXPERIMENTAL
-  if (casync_opts().gemm_pipe != 0)
-    return small ? launch_glds_t<T, 64, 64, 2, 2, 3, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C64x64)
-                 : launch_glds_t<T, 128, 64, 2, 2, 3, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C128x64);
-#endif
   return small ? launch_glds_t<T, 64, 64, 2, 2, 2, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C64x64)
                : launch_glds_t<T, 128, 64, 2, 2, 2, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C128x64);
 }
@@ -1126,7 +1043,7 @@ const char* conv3x3_gemm_kernel_name(int batch, int h, int wdt, int cin, int cou
   const int cfg = pick_cfg(m, cout, 9 * cin, stream_k, dtype, nullptr, concurrent);   // the launch's own choice
   const bool small = cfg == C64x64 || cout % 64 || m <= 4096;
   snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, 2, 2, %d, true>", dtype == DT_BF16 ? "__bf16" : "float",
-             small ? "64, 64" : "128, 64", gemm_pipe_opt() != 0 ? 3 : 2);
+             small ? "64, 64" : "128, 64", 2);
   return buf;
 }
 

@@ -1,6 +1,5 @@
-// Device helpers shared by the two fused inverted-residual kernels (ir_fused.hip: one tile per workgroup, any
-// shape; ir_stream.hip: row-streaming strips for the plan's aligned shapes): LDS tile addressing, the 16x16x4 fp32
-// MFMA and the LeakyReLU idiom.
+// Device helpers of the fused inverted-residual kernels (ir_fused.hip): LDS tile addressing, the 16x16x4 fp32 MFMA and
+// the LeakyReLU idiom.
 #pragma once
 #include "common.h"
 

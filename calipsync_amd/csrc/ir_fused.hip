@@ -878,7 +878,6 @@ extern "C" int casync_debug_ir_stamps(void* dev_words) {
   g_ir_stamps = static_cast<unsigned long long*>(dev_words);
   return CASYNC_OK;
 }
-unsigned long long* casync_ir_stamps() { return g_ir_stamps; }   // ir_stream.hip stamps the same buffer
 
 bool ir_fused_supported(int cin, int cout, int stride) {
   const int key = cin * 10000 + cout * 10 + stride;
@@ -908,9 +907,6 @@ int launch_ir_fused_up(const void* lo, int ld_lo, int c_lo, const void* in, int 
   CASYNC_REQUIRE(c_lo > 0 && c_lo < cin && c_lo % 16 == 0 && ld_lo >= c_lo && ld_lo % 4 == 0, "ir_fused_up: bad c_lo/ld_lo");
   CASYNC_REQUIRE(ld_in >= cin && ld_in % 4 == 0 && ld_out >= cout && ld_out % 4 == 0, "ir_fused_up: bad ld");
   CASYNC_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)lo % 16) == 0, "ir_fused_up: alignment");
-  if (dtype == DT_F32 && casync_opts().ir_stream && ir_stream_supported(cin, cout, 1, h, w, true, 0))
-    return launch_ir_stream(lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out, batch, h, w, cin, cout, 1, 0, true,
-                            stream);
   if (cin == 64 && cout == 32)
     return launch_inst<64, 128, 32, 1, 16, true>(dtype, lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2, out,
                                                  ld_out, batch, h, w, 0, stream);
@@ -947,8 +943,6 @@ const char* ir_fused_upg_kernel_name(int cin, int cout) {
 
 const char* ir_fused_kernel_name(int cin, int cout, int stride, int dtype, bool ups, int h, int w) {
   static thread_local char buf[64];
-  if (dtype == DT_F32 && h > 0 && casync_opts().ir_stream && ir_stream_supported(cin, cout, stride, h, w, ups, cin == cout && stride == 1))
-    return ir_stream_kernel_name(cin, cout, stride, ups);
   if (dtype == DT_BF16)
     snprintf(buf, sizeof(buf), "ir_fused_bf16_kernel<%d, %d, %d, %d, %s>", cin, 2 * cin, cout, stride, ups ? "true" : "false");
   else
@@ -965,9 +959,6 @@ int launch_ir_fused(const void* in, int ld_in, const void* w1, const float* b1, 
   CASYNC_REQUIRE(ld_in >= cin && ld_in % 4 == 0 && ld_out >= cout && ld_out % 4 == 0, "ir_fused: bad ld");
   CASYNC_REQUIRE(!res || (stride == 1 && cin == cout), "ir_fused: residual needs stride 1 and cin == cout");
   CASYNC_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0, "ir_fused: alignment");
-  if (dtype == DT_F32 && casync_opts().ir_stream && ir_stream_supported(cin, cout, stride, h, w, false, res))
-    return launch_ir_stream(nullptr, 0, 0, in, ld_in, w1, b1, wd, bd, w2, b2, out, ld_out, batch, h, w, cin, cout, stride, res,
-                            false, stream);
 #define IR_CASE(CI, CO, S)                                                                          \
   if (cin == CI && cout == CO && stride == S)                                                       \
     return launch_inst<CI, 2 * CI, CO, S, 16>(dtype, nullptr, 0, 0, in, ld_in, w1, b1, wd, bd, w2, b2, \

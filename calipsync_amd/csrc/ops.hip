@@ -152,31 +152,6 @@ __global__ __launch_bounds__(256) void dw3x3_lds_kernel(const T* __restrict__ in
   }
 }
 
-#ifdef CASYNC_EXPERIMENTAL
-// ---------------------------------------------------------------- im2col (dense 3x3)
-template <typename T>
-__global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ in,
-                                                        T* __restrict__ out, int H, int W,
-                                                        int C, int Ho, int Wo, int stride, int pad,
-                                                        long long total) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int c4n = C >> 2;
-  const int c = (int)(idx % c4n) * 4;
-  long long t = idx / c4n;
-  const int tap = (int)(t % 9);
-  t /= 9;  // t = output pixel row m
-  const int ox = (int)(t % Wo);
-  const long long t2 = t / Wo;
-  const int oy = (int)(t2 % Ho);
-  const int b = (int)(t2 / Ho);
-  const int iy = oy * stride - pad + tap / 3, ix = ox * stride - pad + tap % 3;
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = ld4(in + (((size_t)b * H + iy) * W + ix) * C + c);
-  st4(out + (size_t)t * 9 * C + (size_t)tap * C + c, v);
-}
-
-#endif   // CASYNC_EXPERIMENTAL (im2col: the implicit-GEMM convolution replaced it)
 
 // ---------------------------------------------------------------- bilinear x2
 // align_corners=True: src = dst * (in-1)/(out-1); weights as ATen computes them
@@ -501,28 +476,6 @@ int launch_dw3x3(const void* in, const float* w, const float* bias, void* out, i
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }
-
-#ifdef CASYNC_EXPERIMENTAL
-int launch_im2col3x3(const void* in, void* out, int batch, int h, int wdt, int c, int stride,
-                     int pad, hipStream_t stream, int dtype) {
-  CASYNC_REQUIRE(in && out && batch > 0 && c % 4 == 0, "im2col: bad args");
-  const int ho = (h + 2 * pad - 3) / stride + 1, wo = (wdt + 2 * pad - 3) / stride + 1;
-  const long long total = (long long)batch * ho * wo * 9 * (c / 4);
-  DT_DISPATCH(dtype,
-              hipLaunchKernelGGL(im2col3x3_kernel<float>, dim3(blocks_for(total)), dim3(256), 0, stream,
-                                 (const float*)in, (float*)out, h, wdt, c, ho, wo, stride, pad, total),
-              hipLaunchKernelGGL(im2col3x3_kernel<bf16_t>, dim3(blocks_for(total)), dim3(256), 0, stream,
-                                 (const bf16_t*)in, (bf16_t*)out, h, wdt, c, ho, wo, stride, pad, total));
-  CASYNC_CHECK_HIP(hipGetLastError());
-  return CASYNC_OK;
-}
-#else
-int launch_im2col3x3(const void*, void*, int, int, int, int, int, int, hipStream_t, int) {
-  casync_set_error("im2col3x3: this library was built without CASYNC_EXPERIMENTAL (the implicit-GEMM convolution "
-                   "casync_op_conv3x3 replaced the im2col path)");
-  return CASYNC_ERR_STATE;
-}
-#endif
 
 int launch_upsample2x(const void* in, void* out, int ldc, int batch, int h, int wdt, int c,
                       hipStream_t stream, int dtype) {

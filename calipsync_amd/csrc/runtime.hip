@@ -22,9 +22,6 @@ const OptField kFields[] = {
     {"gemm_streamk", &CasyncOptions::gemm_streamk},
     {"gemm_glds", &CasyncOptions::gemm_glds},
     {"gemm_cfg", &CasyncOptions::gemm_cfg},
-    {"gemm_pipe", &CasyncOptions::gemm_pipe},
-    {"gemm_arow", &CasyncOptions::gemm_arow},
-    {"gemm_wide", &CasyncOptions::gemm_wide},
     {"gemm_persist", &CasyncOptions::gemm_persist},
     {"lane_streamk", &CasyncOptions::lane_streamk},
     {"gemm_conc", &CasyncOptions::gemm_conc},
@@ -36,15 +33,8 @@ const OptField kFields[] = {
     {"ups_commute", &CasyncOptions::ups_commute},
     {"fuse_dw", &CasyncOptions::fuse_dw},
     {"fuse_dw_min40", &CasyncOptions::fuse_dw_min40},
-    {"ir_stream", &CasyncOptions::ir_stream},
-    {"ir_stream_min", &CasyncOptions::ir_stream_min},
-    {"ir_stream_stagger", &CasyncOptions::ir_stream_stagger},
-    {"ir_stream_skew", &CasyncOptions::ir_stream_skew},
-    {"ir_stream_wgs", &CasyncOptions::ir_stream_wgs},
-    {"ir_stream_prio", &CasyncOptions::ir_stream_prio},
     {"dw_lds", &CasyncOptions::dw_lds},
     {"dw_lds_bytes", &CasyncOptions::dw_lds_bytes},
-    {"conv_im2col", &CasyncOptions::conv_im2col},
     {"att_nz", &CasyncOptions::att_nz},
 };
 

@@ -317,7 +317,7 @@ class Model(nn.Module):
                 self._engine, x.contiguous().data_ptr(), audio_feat.contiguous().data_ptr(),
                 out.data_ptr(), batch, ws.data_ptr(), ws.numel(), stream, arr, 1024),
                 "casync_profile_forward")
-        return [{"name": arr[i].name.decode(), "kernel": arr[i].kernel.decode(), "ms": arr[i].ms, "flops": arr[i].flops,
+        return [{"name": arr[i].name.decode(), "kernel": arr[i].kernel.decode(), "ms": arr[i].ms, "ms_raw": arr[i].ms_raw, "flops": arr[i].flops,
                  "bytes": arr[i].bytes} for i in range(n)]
 
     def __del__(self):

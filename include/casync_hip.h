@@ -43,14 +43,8 @@ enum {
 /* ---- introspection (callable without a GPU) --------------------------- */
 /* Bumped on every change of a prototype, struct layout or the packed-weight layout; the ctypes
  * host (calipsync_amd/_lib.py) refuses a library whose version differs from the one it binds.   */
-#define CASYNC_ABI_VERSION 3
+#define CASYNC_ABI_VERSION 4
 int         casync_abi_version(void);
-/* How the library was built.  CASYNC_BUILD_EXPERIMENTAL: it also contains the kernels that were measured and not
- * adopted (two bf16 GEMM designs, deeper GEMM rings, extra tile shapes, the im2col convolution); their switches
- * (casync_set_option: gemm_arow, gemm_wide, gemm_pipe, conv_im2col, gemm_cfg >= 4) and casync_op_im2col3x3 return
- * CASYNC_ERR_STATE in a product build.                                                                          */
-#define CASYNC_BUILD_EXPERIMENTAL 1
-int         casync_build_flags(void);
 const char* casync_last_error(void);           /* thread-local message         */
 
 /* Packed-weight layout.  The host folds eval-mode BatchNorm into the conv /
@@ -127,7 +121,8 @@ int64_t casync_tap(casync_handle h, const char* name, int batch, void* workspace
 typedef struct {
   char  name[48];     /* plan step, e.g. "up4.conv.double_conv.0.fused"      */
   char  kernel[64];   /* HIP kernel instance as rocprofv3 names it           */
-  float ms;
+  float ms;           /* event-pair time minus the calibrated cost of an empty pair (clamped at 0) */
+  float ms_raw;       /* the event-pair time as measured                     */
   double flops;       /* algorithmic flops of this launch                   */
   double bytes;       /* algorithmic bytes (inputs read once + outputs)     */
 } casync_kernel_time;
@@ -206,10 +201,6 @@ int casync_op_ir_fused_upg(const float* g, int ld_g, const float* in, int ld_in,
                            const float* b1, const float* wd, const float* bd, const float* w2,
                            const float* b2, float* out, int ld_out, int batch, int h, int w, int cin,
                            int cout, casync_stream stream);
-/* im2col for the two dense 3x3 stride-2 convs (module/unet.py:161-168):
- * out[B*Ho*Wo][9*C], column order (ky,kx,c).                                */
-int casync_op_im2col3x3(const void* in, void* out, int batch, int h, int wdt, int c,
-                        int stride, int pad, casync_stream stream);
 /* Bilinear x2, align_corners=True (module/unet.py:86-87,91), NHWC, writing
  * into a wider row (ldc) so the concat with the skip is free.               */
 int casync_op_upsample2x(const void* in, void* out, int ldc, int batch, int h, int wdt,

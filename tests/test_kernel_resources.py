@@ -48,8 +48,6 @@ def table():
     build.build()                      # no-op when the library is up to date
     if not os.path.isdir(kernel_resources.OBJ_DIR) or not any(f.endswith(".o") for f in os.listdir(kernel_resources.OBJ_DIR)):
         build.build(force=True)        # a library shipped without its objects: compile them
-    if build.EXPERIMENTAL:
-        pytest.skip("budgets are pinned for the product build")
     return kernel_resources.table()
 
 

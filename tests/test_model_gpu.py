@@ -83,9 +83,12 @@ def test_golden_b_intermediates(net_b, golden_b, name):
     assert d < 2e-5, (name, d)
 
 
-@pytest.mark.parametrize("batch", [1, 3, 64])
+@pytest.mark.parametrize("batch", [1, 3, 8, 12, 16, 24, 64])
 def test_against_oracle(net, recipe_sd, batch):
-    """configs[0]/[1] of BASELINE.json: B=1 plumbing and B=64 fp32 vs the CPU path."""
+    """configs[0]/[1] of BASELINE.json: B=1 plumbing and B=64 fp32 vs the CPU path; and the reference's own batch
+    sizes -- FrameSynthesizer(batch_size=8) (image_infer_v1/tools/frame_synthesizer/infer_api.py:13-14), its B=8
+    self-benchmark (image_infer_v1/models/unet.py:342-347), README's 8-16 -- which sit on the engine's plan switches
+    (40x40 strips from 8 frames per launch, whole-frame expand+depthwise tiles from 16, two lanes from 32)."""
     from oracle import unet_oracle
     torch.set_num_threads(16)
     sd = unet_oracle.to_torch(recipe_sd)
@@ -96,6 +99,48 @@ def test_against_oracle(net, recipe_sd, batch):
     d = float((out - ref).abs().max())
     print(f"B={batch} max|d| vs oracle: {d:.3e}")
     assert d < TOL and d < EXPECT
+
+
+def test_default_plan_intermediates_against_oracle(net, recipe_sd):
+    """The benched plan (B=64: two lanes of 32, pw_dw tiles / strips, commuted upsample, 64x64 tiles) tap by tap: every
+    named intermediate of frames {0, 31, 32, 63} -- first and last frame of both lanes -- against the oracle's taps of
+    exactly those frames (the golden taps are B=2/3 fixtures, where none of those kernels is selected)."""
+    from oracle import unet_oracle
+    x, a = recipe.make_inputs_range(300, 64)
+    out = net(torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda())
+    got = {name: net.tap(name, 64).cpu() for name in TAPS}
+    pick = [0, 31, 32, 63]
+    ref = {}
+    torch.set_num_threads(16)
+    ref_out = unet_oracle.forward(unet_oracle.to_torch(recipe_sd), torch.from_numpy(x[pick]), torch.from_numpy(a[pick]), ref)
+    assert float((out[pick].cpu() - ref_out).abs().max()) < EXPECT
+    worst = {}
+    for name in TAPS:
+        r, g = ref[name], got[name][pick]
+        assert r.shape == g.shape, name
+        worst[name] = float((g - r).abs().max()) / max(1.0, float(r.abs().max()))
+    print("B=64 taps vs oracle, max rel:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert max(worst.values()) < 2e-5, worst
+
+
+@pytest.mark.parametrize("opts", [dict(fuse_up=0), dict(fuse_up=0, ups_commute=0), dict(ups_commute=0), dict(ups_commute=1),
+                                  dict(fuse_ir=0), dict(fuse_ir=0, ups_commute=0), dict(fuse_dw=0), dict(fuse_min_hw=80)])
+@pytest.mark.parametrize("batch", [3, 20])
+def test_plan_switches_against_oracle(recipe_sd, opts, batch):
+    """Every documented plan switch of the Up / inverted-residual stages gives the oracle's output (the workspace is sized
+    from the same predicates the plan uses: an un-fused up4.0 needs a 160x160x128 expand buffer)."""
+    from oracle import unet_oracle
+    m = Model(6, "hubert").to("cuda:0")
+    for k, v in opts.items():
+        m.set_option(k, v)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe_sd.items()})
+    x, a = recipe.make_inputs_range(40, batch)
+    out = m(torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda())
+    pick = [0, batch - 1]
+    torch.set_num_threads(16)
+    ref = unet_oracle.forward(unet_oracle.to_torch(recipe_sd), torch.from_numpy(x[pick]), torch.from_numpy(a[pick]))
+    d = float((out[pick].cpu() - ref).abs().max())
+    assert d < EXPECT, (opts, d)
 
 
 def test_frames_independent_and_batch_invariant(net):

@@ -12,19 +12,6 @@ from gpu_util import dev, nchw, nhwc, ok, options, ptr, stream
 pytestmark = pytest.mark.gpu
 
 
-def needs_experimental(fn):
-    """Tests of the kernels that were measured and not adopted: they only exist in a library built with
-    CASYNC_EXPERIMENTAL=1 (VERDICT r2 #8: the product library contains what the default plan can run)."""
-    import functools
-
-    @functools.wraps(fn)
-    def wrapper(*args, **kwargs):
-        if not _lib.experimental():
-            pytest.skip("library built without CASYNC_EXPERIMENTAL")
-        return fn(*args, **kwargs)
-    return wrapper
-
-
 def rel_err(got, ref):
     return float((got - ref).abs().max() / max(1e-6, float(ref.abs().max())))
 
@@ -156,29 +143,6 @@ def test_dw3x3(lib, b, h, w, c, stride):
     out = torch.empty(b, ref.shape[2], ref.shape[3], c, device=dev())
     ok(lib.casync_op_dw3x3(ptr(xd), ptr(wp), ptr(bd), ptr(out), b, h, w, c, stride, stream()))
     assert rel_err(nchw(out), ref) < 2e-6
-
-
-@pytest.mark.parametrize("h,c,stride,padv,cout", [(32, 128, 2, 1, 256), (16, 256, 2, 3, 512)])
-@needs_experimental
-def test_dense3x3_via_im2col(lib, h, c, stride, padv, cout):
-    """conv3 (pad 1) and conv5 (pad 3: 16 -> 10) of the audio encoder."""
-    g = torch.Generator().manual_seed(h)
-    b = 2
-    x = torch.randn(b, c, h, h, generator=g)
-    wt = torch.randn(cout, c, 3, 3, generator=g) / (3 * c ** 0.5)
-    bias = torch.randn(cout, generator=g)
-    ref = F.leaky_relu(F.conv2d(x, wt, bias, stride, padv), 0.01)
-    ho = ref.shape[2]
-    assert ho == (10 if padv == 3 else 16)
-    xd = nhwc(x)
-    col = torch.empty(b * ho * ho, 9 * c, device=dev())
-    ok(lib.casync_op_im2col3x3(ptr(xd), ptr(col), b, h, h, c, stride, padv, stream()))
-    wp = wt.permute(0, 2, 3, 1).reshape(cout, 9 * c).contiguous().to(dev())
-    out = torch.empty(b * ho * ho, cout, device=dev())
-    bd = bias.to(dev())
-    ok(lib.casync_op_pw_gemm(ptr(col), 9 * c, ptr(wp), ptr(bd), ptr(out), cout, b * ho * ho, cout, 9 * c, 1,
-                             0, 0, 0, 0, 0, 0, 0, stream()))
-    assert rel_err(nchw(out.view(b, ho, ho, cout)), ref) < 3e-6
 
 
 @pytest.mark.parametrize("b,h,w,c,stride,padv,cout", [(2, 32, 32, 128, 2, 1, 256), (2, 16, 16, 256, 2, 3, 512),
@@ -461,62 +425,6 @@ def test_up_block_expand_with_commuted_upsample(lib, hw, c_lo, cexp, frames, fus
     assert rel_err(out.permute(0, 3, 1, 2).cpu(), ref) < 3e-6
 
 
-STREAM_CASES = [  # (state_dict prefix, cin, cout, res, ups, h, w, batch): the instances ir_stream.hip builds
-    ("up4.conv.double_conv.0", 64, 32, False, False, 48, 32, 3),
-    ("up4.conv.double_conv.0", 64, 32, False, True, 48, 32, 3),
-    ("up4.conv.double_conv.0", 64, 32, False, True, 160, 160, 1),
-    ("up4.conv.double_conv.1", 32, 32, True, False, 56, 48, 3),
-]
-
-
-@pytest.mark.parametrize("min_steps", [1, 2, 5, 1000])
-@pytest.mark.parametrize("prefix,cin,cout,res,ups,h,w,b", STREAM_CASES)
-@needs_experimental
-def test_ir_stream_equals_tile_kernel(lib, recipe_sd, prefix, cin, cout, res, ups, h, w, b, min_steps):
-    """The row-streaming kernel (ir_stream.hip) against the tile kernel (ir_fused.hip, ir_stream=0) and the oracle:
-    same products in the same order, so the two kernels agree BIT FOR BIT -- for every way of cutting the step list
-    into workgroup runs (min_steps 1: every step starts fresh, 2 / 5: runs carry rows, cross strips and frames,
-    1000: one workgroup walks everything), with strided channel-slice operands."""
-    from oracle import unet_oracle
-    sd = unet_oracle.to_torch(recipe_sd)
-    f = pack.fold(recipe_sd)
-    g = torch.Generator().manual_seed(h * 11 + cin + int(ups))
-    T = lambda k: torch.from_numpy(f[f"{prefix}.{k}"].astype(np.float32)).contiguous().to(dev())
-    w1, b1, wd, bd, w2, b2 = T("pw1.w"), T("pw1.b"), T("dw.w"), T("dw.b"), T("pw2.w"), T("pw2.b")
-    ld_in, ld_out = cin + 16, cout + 16
-    if ups:
-        c_lo = cin // 2
-        lo = torch.randn(b, c_lo, h // 2, w // 2, generator=g)
-        skip = torch.randn(b, cin - c_lo, h, w, generator=g)
-        x = torch.cat([F.interpolate(lo, scale_factor=2, mode="bilinear", align_corners=True), skip], 1)
-        xin = torch.full((b, h, w, ld_in), 77.0)                 # the upsampled half is never materialised
-        xin[..., 16 + c_lo:] = skip.permute(0, 2, 3, 1)
-        lod = nhwc(lo)
-    else:
-        x = torch.randn(b, cin, h, w, generator=g)
-        xin = torch.full((b, h, w, ld_in), 3.0)
-        xin[..., 16:] = x.permute(0, 2, 3, 1)
-    ref = unet_oracle.inverted_residual(sd, prefix, x, 1, res)
-    xin = xin.to(dev())
-    outs = []
-    for use_stream in (1, 0):
-        out = torch.full((b, h, w, ld_out), -5.0, device=dev())
-        with options(ir_stream=2 * use_stream, ir_stream_min=min_steps):      # 2: also where the tile kernel is the default
-            if ups:
-                ok(lib.casync_op_ir_fused_up(ptr(lod), c_lo, c_lo, xin.data_ptr() + 16 * 4, ld_in, ptr(w1), ptr(b1), ptr(wd),
-                                             ptr(bd), ptr(w2), ptr(b2), out.data_ptr() + 16 * 4, ld_out, b, h, w, cin, cout,
-                                             stream()))
-            else:
-                ok(lib.casync_op_ir_fused(xin.data_ptr() + 16 * 4, ld_in, ptr(w1), ptr(b1), ptr(wd), ptr(bd), ptr(w2), ptr(b2),
-                                          out.data_ptr() + 16 * 4, ld_out, b, h, w, cin, cout, 1, int(res), stream()))
-        o = out.cpu()
-        assert (o[..., :16] == -5).all()
-        outs.append(o[..., 16:].permute(0, 3, 1, 2))
-        assert rel_err(outs[-1], ref) < 5e-6, (use_stream, rel_err(outs[-1], ref))
-    assert torch.equal(outs[0], outs[1])
-
-
-# ------------------------------------------------------------------ bf16 storage (BASELINE configs[2])
 @pytest.fixture()
 def bf16_ops(lib):
     lib.casync_op_set_dtype(1)
@@ -542,66 +450,6 @@ def test_pw_gemm_bf16(bf16_ops, m, n, k):
     assert float(err.max()) < 2 ** -8, float(err.max())
 
 
-def _bf16_big_gemm_check(lib, m, n, k, cfg, switch):
-    """One of the two large-M bf16 kernels (cfg 6 = 256x128 persistent ring, 7 = A-stationary) with every epilogue
-    option at once and operands / result as slices of wider buffers: equal to an fp64 reference to 2^-8 relative,
-    one bf16 ulp from the 128x128 kernel on the same operands, bit-repeatable, nothing written outside the slice;
-    `switch` = the option that makes the engine pick that kernel by itself."""
-    g = torch.Generator().manual_seed(m + n + k)
-    lda, ldc = k + 64, n + 32
-    abuf = torch.randn(m, lda, generator=g).bfloat16()
-    w = (torch.randn(n, k, generator=g) / k ** 0.5).bfloat16()
-    bias, ps, s2, t2 = (torch.randn(n, generator=g) for _ in range(4))
-    pre, post = torch.randn(m, n, generator=g).bfloat16(), torch.randn(m, n + 32, generator=g).bfloat16()
-    a = abuf[:, 64:64 + k]
-    v = a.double() @ w.double().T + bias.double() + ps.double() * pre.double()
-    v = F.leaky_relu(v, 0.01) + post[:, :n].double()
-    ref = F.leaky_relu(v * s2.double() + t2.double(), 0.01)
-    D = lambda t: t.to(dev())
-    abuf_d, wd, bd, psd, s2d, t2d, pred, postd = map(D, (abuf, w, bias, ps, s2, t2, pre, post))
-
-    def run(out_buf):
-        ok(lib.casync_op_pw_gemm(abuf_d.data_ptr() + 64 * 2, lda, ptr(wd), ptr(bd), out_buf.data_ptr() + 16 * 2, ldc, m, n, k,
-                                 1, ptr(pred), n, ptr(psd), ptr(postd), n + 32, ptr(s2d), ptr(t2d), stream()))
-    outs = []
-    for opts in ({"gemm_cfg": cfg}, {"gemm_cfg": 0}, {"gemm_cfg": -1, **switch}):
-        cbuf = torch.full((m, ldc), -7.0, device=dev(), dtype=torch.bfloat16)
-        with options(**opts):
-            run(cbuf)
-        out = cbuf.cpu()
-        assert (out[:, :16] == -7).all() and (out[:, 16 + n:] == -7).all()     # nothing outside the slice
-        outs.append(out[:, 16:16 + n].double())
-        err = (outs[-1] - ref).abs() / (ref.abs() + 1.0)
-        assert float(err.max()) < 2 ** -8, (opts, float(err.max()))
-    # two roundings of nearly equal fp32 sums can land one bf16 ulp (2^-7 relative) apart
-    assert float(((outs[0] - outs[1]).abs() / (ref.abs() + 1.0)).max()) < 2 ** -7
-    assert float(((outs[0] - outs[2]).abs() / (ref.abs() + 1.0)).max()) < 2 ** -7
-    cbuf2 = torch.full((m, ldc), -7.0, device=dev(), dtype=torch.bfloat16)
-    with options(gemm_cfg=cfg):
-        for _ in range(2):      # bit-repeatable, and a second launch right behind the first sees clean state
-            run(cbuf2)
-    assert torch.equal(cbuf2.cpu()[:, 16:16 + n].double(), outs[0])
-
-
-@pytest.mark.parametrize("m,n,k", [(65536, 128, 256), (16384, 512, 512), (25600, 1024, 512), (16384, 640, 1024),
-                                   (8192, 1024, 4096)])
-@needs_experimental
-def test_pw_gemm_bf16_wide_kernel(bf16_ops, m, n, k):
-    """The 256x128 persistent ring kernel (>= 256 tiles): several tiles per workgroup, so the ring runs across
-    tile boundaries and epilogues."""
-    assert (m // 256) * (n // 128) >= 256
-    _bf16_big_gemm_check(bf16_ops, m, n, k, 6, {"gemm_wide": 2})
-
-
-@pytest.mark.parametrize("m,n,k", [(65536, 128, 256), (16384, 512, 512), (25600, 1024, 512), (16384, 640, 256),
-                                   (32768, 2304, 512)])
-@needs_experimental
-def test_pw_gemm_bf16_a_stationary_kernel(bf16_ops, m, n, k):
-    """The A-stationary kernel: A rows in registers, W streamed chunk by chunk; several chunks per workgroup."""
-    _bf16_big_gemm_check(bf16_ops, m, n, k, 7, {"gemm_arow": 1})
-
-
-@needs_experimental
 def test_pw_gemm_bf16_wide_kernel_plain(bf16_ops):
     """No epilogue arithmetic: the wide kernel and the 128x128 kernel add the same products in the same k order."""
     lib = bf16_ops
@@ -690,15 +538,3 @@ def test_dw3x3_bf16(bf16_ops, b, h, w, c, stride):
     ok(lib.casync_op_dw3x3(ptr(xd), ptr(wp), ptr(bd), ptr(out), b, h, w, c, stride, stream()))
     assert rel_err(nchw(out.float()), ref) < 2 ** -8
 
-
-def test_product_build_refuses_experimental_switches(lib):
-    """In a product build the switches of the quarantined kernels can only be 'off', and say why."""
-    if _lib.experimental():
-        pytest.skip("experimental build: the switches are live")
-    for name, value in (("gemm_arow", 1), ("gemm_wide", 1), ("gemm_pipe", 3), ("conv_im2col", 1), ("gemm_cfg", 6), ("ir_stream", 1)):
-        with pytest.raises(RuntimeError, match="CASYNC_EXPERIMENTAL"):
-            _lib.set_option(name, value)
-        _lib.set_option(name, 0 if name != "gemm_cfg" else -1)       # 'off' is always accepted
-    z = torch.zeros(64, device=dev())
-    assert lib.casync_op_im2col3x3(ptr(z), ptr(z), 1, 4, 4, 4, 1, 1, stream()) < 0
-    assert b"CASYNC_EXPERIMENTAL" in lib.casync_last_error()
