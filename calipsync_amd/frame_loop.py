@@ -285,6 +285,7 @@ def submit_batch_device(net, batch_images, batch_landmarks, batch_masks, *, wind
     geom = np.zeros((B, GEOM_WORDS), dtype=np.int32)
     pts = np.zeros((B, 33, 2), dtype=np.int32)
     boxes, regions, fmasks = [], [], []      # fmasks: (frame, array) to upload with this batch
+    held_masks: list = []                    # cached device masks this batch reads (kept alive until it is enqueued)
     reg_off = synth_off = mask_off = fmask_bytes = 0
     cache = _mask_cache(net) if mask_keys is not None else None
     if mask_keys is not None and len(mask_keys) != B:
@@ -314,6 +315,7 @@ def submit_batch_device(net, batch_images, batch_landmarks, batch_masks, *, wind
             hit = cache.get(key) if key is not None else None
             if hit is not None:
                 cache.move_to_end(key)
+                held_masks.append(hit)           # the geometry record holds its raw address: see the eviction below
                 g[10], g[11] = _split64(hit.data_ptr())
             else:
                 m = np.ascontiguousarray(mask, dtype=np.uint8 if kind else np.float32)
@@ -367,8 +369,15 @@ def submit_batch_device(net, batch_images, batch_landmarks, batch_masks, *, wind
         for i, key, m, off in fmasks:     # named masks move into allocations of their own and stay (device-side copy)
             if key is not None:
                 keep = staged[o_fm + off:o_fm + off + m.nbytes].clone()
+                old = cache.pop(key, None)
+                if old is not None:
+                    net._mask_cache_bytes -= old.numel()
                 cache[key] = keep
                 net._mask_cache_bytes += keep.numel()
+        # Eviction only drops the CACHE's reference.  A mask this batch hit stays alive through `held_masks` until every
+        # kernel of the batch is enqueued; torch's allocator is stream-ordered, so a block freed after that can only be
+        # reused by work that runs behind those kernels (evicting first let `crops` / `x` land on a mask the
+        # blend kernel was still going to read).
         while cache is not None and net._mask_cache_bytes > _MASK_CACHE_CAP and len(cache) > 1:
             net._mask_cache_bytes -= cache.popitem(last=False)[1].numel()
         crops = torch.empty((B, 168, 168, 3), dtype=torch.uint8, device=dev)
@@ -394,4 +403,5 @@ def submit_batch_device(net, batch_images, batch_landmarks, batch_masks, *, wind
         done.record(torch.cuda.current_stream(dev))
     # device tensors may be dropped here (torch's allocator is stream-ordered on the current stream); the two
     # pinned buffers are ours until the event has passed, i.e. until result()
+    del held_masks
     return PendingBatch(copies, boxes, geom, host, done, stage)

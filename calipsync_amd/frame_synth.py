@@ -15,9 +15,10 @@ and ONE download per batch instead of per-frame cv2 calls and B separate ``.cpu(
 uploaded once and the 16-step windows are gathered on the device (``Model.forward_windows``) instead
 of being materialised on the host per batch (infer_api.py:99-145, 257).
 
-Frame sequencing (the ping-pong "motion generalisation" walk, infer_api.py:147-190) is restated
-statement by statement; the only addition is an optional ``seed`` so a run can be reproduced (the
-reference draws from the unseeded module-level ``random``).  File I/O (``cv2.imread`` /
+Frame sequencing (the ping-pong "motion generalisation" walk, infer_api.py:147-190) is
+``frame_walk.PingPongWalk``: the same sequence for the same random draws, produced from one phase counter; the
+only addition is an optional ``seed`` so a run can be reproduced (the reference draws from the unseeded
+module-level ``random``).  File I/O (``cv2.imread`` /
 ``np.loadtxt``, infer_api.py:52-97) stays host code behind the same methods; where cv2 is not
 installed JPEGs are decoded with Pillow (same libjpeg, BGR order restored).
 """
@@ -33,6 +34,7 @@ import numpy as np
 import torch
 
 from . import frame_loop
+from .frame_walk import PingPongWalk
 from .unet import Model
 
 
@@ -76,13 +78,9 @@ class FrameSynthesizer:
             net = Model(6, "hubert", precision=precision).to(device)
             net.load_state_dict(torch.load(unet_checkpoint, map_location="cpu"))
         self.net = net.eval()
-        # frame-walk state (infer_api.py:46-50)
-        self.current_direction = None
-        self.target_frame_count = 0
-        self.processed_frame_count = 0
-        self.current_frame_position = 0
+        # frame-walk state (infer_api.py:46-50); the reference draws from the module-level random
+        self._walk = PingPongWalk(self.total_frames, random.Random(seed) if seed is not None else None)
         self.last_logical_index = -1
-        self._rng = random.Random(seed) if seed is not None else random   # reference: module-level random
         self._features_dev = None        # (id of the host array, device copy) of the clip being synthesised
 
     # ------------------------------------------------------------------ file I/O (infer_api.py:52-97)
@@ -90,28 +88,20 @@ class FrameSynthesizer:
         """(image, landmarks, mask) of a frame, as the reference returns them (mask = gray image / 255 in float32).
         ``raw_mask`` (this loop's own calls): the mask stays the uint8 image -- the device divides by 255 in float32,
         the same bits at a quarter of the bytes, and the host skips an 8 MB conversion per 1080p frame."""
-        frame_number = str(frame_idx % self.total_frames).zfill(6)
-        img = _imread(os.path.join(self.frames_dir, f"{frame_number}{self._ext}"))
-        lms = np.loadtxt(os.path.join(self.positions_dir, f"{frame_number}.txt"))
-        mask = None
-        for ext in (".jpg", ".npy"):
-            mask_path = os.path.join(self.masks_dir, f"{frame_number}{ext}")
-            if os.path.exists(mask_path):
-                mask = _imread(mask_path, gray=True)
-                if mask is not None and not (raw_mask and mask.dtype == np.uint8):
-                    mask = mask.astype(np.float32) / 255.0
-                break
+        stem = f"{frame_idx % self.total_frames:06d}"
+        img = _imread(os.path.join(self.frames_dir, stem + self._ext))
+        lms = np.loadtxt(os.path.join(self.positions_dir, stem + ".txt"))
+        mask_path = next((p for p in (os.path.join(self.masks_dir, stem + ext) for ext in (".jpg", ".npy")) if os.path.exists(p)), None)
+        mask = _imread(mask_path, gray=True) if mask_path else None
+        if mask is not None and not (raw_mask and mask.dtype == np.uint8):
+            mask = mask.astype(np.float32) / 255.0          # float32 division, as the reference (infer_api.py:68)
         return img, lms, mask
 
     def _load_batch_frames(self, frame_indices: list, raw_masks: bool = False) -> tuple:
-        futures = [self.executor.submit(self._load_single_frame, i, raw_masks) for i in frame_indices]
-        batch_images, batch_landmarks, batch_masks = [], [], []
-        for future in futures:
-            img, lms, mask = future.result()
-            batch_images.append(img)
-            batch_landmarks.append(lms)
-            batch_masks.append(mask)
-        return batch_images, batch_landmarks, batch_masks
+        """(images, landmarks, masks) of the frames, decoded on the I/O pool (infer_api.py:80-97)."""
+        loaded = list(self.executor.map(lambda i: self._load_single_frame(i, raw_masks), frame_indices))
+        images, landmarks, masks = (list(column) for column in zip(*loaded)) if loaded else ([], [], [])
+        return images, landmarks, masks
 
     # ------------------------------------------------------------------ audio windows (infer_api.py:99-145)
     def _get_audio_features(self, features: np.ndarray, indices: list) -> np.ndarray:
@@ -123,29 +113,20 @@ class FrameSynthesizer:
 
     # ------------------------------------------------------------------ frame walk (infer_api.py:147-190)
     def _generate_frame_sequence(self, needed_frames: int) -> list:
-        frame_sequence = []
-        # re-draw direction and run length when the current run is used up (5-15 % of the clip)
-        if self.processed_frame_count >= self.target_frame_count or self.current_direction is None:
-            self.target_frame_count = self.total_frames * self._rng.randint(5, 15) // 100
-            self.current_direction = self._rng.choice([1, -1])
-            self.processed_frame_count = 0
-        while len(frame_sequence) < needed_frames:
-            if self.current_direction == 1:
-                available_frames = self.total_frames - self.current_frame_position
-            else:
-                available_frames = self.current_frame_position + 1
-            seq_length = min(available_frames, needed_frames - len(frame_sequence))
-            for _ in range(seq_length):
-                frame_sequence.append(self.current_frame_position)
-                self.current_frame_position += self.current_direction
-                if self.current_frame_position >= self.total_frames:      # bounce at the end
-                    self.current_frame_position = self.total_frames - 2
-                    self.current_direction = -1
-                elif self.current_frame_position < 0:                     # bounce at the start
-                    self.current_frame_position = 1
-                    self.current_direction = 1
-        self.processed_frame_count += len(frame_sequence)
-        return frame_sequence
+        """The next ``needed_frames`` stored-frame indices of the ping-pong replay (``frame_walk.PingPongWalk``)."""
+        return self._walk.take(needed_frames)
+
+    @property
+    def current_frame_position(self) -> int:      # the reference's attribute names, read-only views of the walk
+        return self._walk.position
+
+    @property
+    def processed_frame_count(self) -> int:
+        return self._walk.run_used
+
+    @property
+    def target_frame_count(self) -> int:
+        return self._walk.run_budget
 
     # ------------------------------------------------------------------ the batch (infer_api.py:192-357)
     def process_batch(self, batch_images: list, batch_landmarks: list, batch_masks: list,
@@ -201,11 +182,8 @@ class FrameSynthesizer:
                     batch_images, batch_landmarks, batch_masks = self._load_batch_frames(
                         frame_sequence, raw_masks=is_generate_sync_frame)
                     time_stats["load_frame"] += time.time() - t0
-                    if not is_generate_sync_frame:
-                        for i, original_image in enumerate(batch_images):
-                            self.last_logical_index += 1
-                            yield {"frame": original_image, "index": self.last_logical_index,
-                                   "physical_index": frame_sequence[i]}
+                    if not is_generate_sync_frame:      # pass-through mode: the stored frames, numbered
+                        yield from self._emit(batch_images, frame_sequence)
                         continue
                     # one batch in flight: batch k+1 is loaded, cropped and enqueued while the GPU works on
                     # batch k, whose frames are yielded afterwards -- same frames, same order
@@ -227,9 +205,7 @@ class FrameSynthesizer:
                 yield from self._drain_one(in_flight, time_stats)
         except Exception as exc:                # fatal: one black frame so the consumer does not hang (:438-446)
             print(f"frame iterator failed: {exc!r}")
-            self.last_logical_index += 1
-            yield {"frame": np.zeros((480, 640, 3), dtype=np.uint8), "index": self.last_logical_index,
-                   "physical_index": 0}
+            yield from self._emit([np.zeros((480, 640, 3), dtype=np.uint8)], [0])
         finally:
             total_time = sum(time_stats.values())
             if total_time > 0:
@@ -242,9 +218,13 @@ class FrameSynthesizer:
         t0 = time.time()
         processed = self._collect(pending, originals)
         time_stats["process_batch"] += time.time() - t0
-        for i, frame in enumerate(processed):
+        yield from self._emit(processed, frame_sequence)
+
+    def _emit(self, frames, physical_indices):
+        """The iterator's items (infer_api.py:400-405): consecutive logical indices over whatever is handed out."""
+        for frame, physical in zip(frames, physical_indices):
             self.last_logical_index += 1
-            yield {"frame": frame, "index": self.last_logical_index, "physical_index": frame_sequence[i]}
+            yield {"frame": frame, "index": self.last_logical_index, "physical_index": physical}
 
     def __del__(self):
         if hasattr(self, "executor"):

@@ -120,18 +120,34 @@ def _stub_net():
 
 
 def test_frame_walk_matches_the_literal_restatement(tmp_path):
+    """FrameSynthesizer's walk (frame_walk.PingPongWalk: one phase counter, whole requests by array arithmetic) against the
+    literal restatement of the reference's loop (oracle FrameWalk): same frames for the same random draws, over clips of
+    2..40 frames, ragged request sizes, many re-draws and turns; and the same run bookkeeping."""
     from calipsync_amd.frame_synth import FrameSynthesizer
+    from calipsync_amd.frame_walk import PingPongWalk
     write_dataset(str(tmp_path), 40, 32, 48)
     for seed in (0, 1, 7, 123):
         fs = FrameSynthesizer(None, str(tmp_path), device="cpu", batch_size=8, seed=seed, net=_stub_net())
         walk = frame_loop_oracle.FrameWalk(40, random.Random(seed))
-        for need in (8, 8, 3, 8, 8, 8, 40, 1, 8, 8, 5, 64):
+        for need in (8, 8, 3, 8, 8, 8, 40, 1, 8, 8, 5, 64, 0, 2, 200):
             got = fs._generate_frame_sequence(need)
             assert got == walk.generate(need)
             assert len(got) == need and all(0 <= p < 40 for p in got)
             assert all(abs(b - a) <= 1 for a, b in zip(got, got[1:]))          # a walk: +-1, or a bounce (+-1 too)
-        assert (fs.current_direction, fs.current_frame_position, fs.processed_frame_count, fs.target_frame_count) == \
-               (walk.current_direction, walk.current_frame_position, walk.processed_frame_count, walk.target_frame_count)
+            assert (fs.current_frame_position, fs.processed_frame_count, fs.target_frame_count) == \
+                   (walk.current_frame_position, walk.processed_frame_count, walk.target_frame_count)
+    for total in (2, 3, 4, 5, 17, 40):
+        for seed in range(6):
+            mine, ref = PingPongWalk(total, random.Random(seed)), frame_loop_oracle.FrameWalk(total, random.Random(seed))
+            sizes = random.Random(100 + seed)
+            for _ in range(60):
+                n = sizes.choice([1, 2, 3, 8, 8, 8, 16, 5 * total])
+                assert mine.take(n) == ref.generate(n), (total, seed)
+                assert mine.position == ref.current_frame_position
+                if 0 < mine.position < total - 1:                              # at the two ends both directions are the same walk
+                    assert mine.ascending == (ref.current_direction == 1)
+    still = PingPongWalk(1, random.Random(0))                                  # the reference's loop never ends on a one-frame clip
+    assert still.take(5) == [0] * 5 and still.position == 0
 
 
 def test_iterator_contract_without_sync(tmp_path):
@@ -252,6 +268,27 @@ def test_uint8_masks_named_and_resident_equal_float_masks(gpu_net):
     again = frame_loop.process_batch_device(gpu_net, imgs, lms, u8, windows=wd, mask_keys=keys)
     assert all(np.array_equal(a, b) for a, b in zip(again, want))
     assert {k: v.data_ptr() for k, v in gpu_net._mask_cache.items()} == ptrs          # nothing was uploaded again
+
+
+@pytest.mark.gpu
+def test_mask_cache_eviction_keeps_this_batch_masks_alive(gpu_net, monkeypatch):
+    """with a cap smaller than one batch's masks the LRU evicts masks the batch in hand still reads through raw
+    addresses in its geometry records.  The batch must keep them alive: the pixels equal the un-cached run, batch after
+    batch, and the byte count follows overwritten keys."""
+    from calipsync_amd import frame_loop
+    rng = np.random.default_rng(77)
+    imgs, lms, _ = make_frames(6, 300, 400, seed=5)
+    u8 = [rng.integers(0, 256, (300, 400), dtype=np.uint8) for _ in range(6)]
+    wd = torch.from_numpy(rng.standard_normal((6, 32, 32, 32)).astype(np.float32)).cuda()
+    want = frame_loop.process_batch_device(gpu_net, imgs, lms, u8, windows=wd)                 # masks travel with the batch
+    gpu_net.__dict__.pop("_mask_cache", None)
+    monkeypatch.setattr(frame_loop, "_MASK_CACHE_CAP", 2 * 300 * 400 + 1)                       # room for two of six
+    keys = [("clip2", i) for i in range(6)]
+    for _ in range(3):       # 1st: all misses, four evicted; 2nd / 3rd: the survivors hit and are evicted while in use
+        got = frame_loop.process_batch_device(gpu_net, imgs, lms, u8, windows=wd, mask_keys=keys)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+        assert gpu_net._mask_cache_bytes == sum(v.numel() for v in gpu_net._mask_cache.values()) <= 2 * 300 * 400 + 1
+    gpu_net.__dict__.pop("_mask_cache", None)
 
 
 def test_pinned_pool_size_classes_and_cap(monkeypatch):
