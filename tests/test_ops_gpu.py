@@ -450,26 +450,6 @@ def test_pw_gemm_bf16(bf16_ops, m, n, k):
     assert float(err.max()) < 2 ** -8, float(err.max())
 
 
-def test_pw_gemm_bf16_wide_kernel_plain(bf16_ops):
-    """No epilogue arithmetic: the wide kernel and the 128x128 kernel add the same products in the same k order."""
-    lib = bf16_ops
-    m, n, k = 32768, 256, 512
-    g = torch.Generator().manual_seed(11)
-    a = torch.randn(m, k, generator=g).bfloat16()
-    w = (torch.randn(n, k, generator=g) / k ** 0.5).bfloat16()
-    bias = torch.randn(n, generator=g)
-    ref = a.double() @ w.double().T + bias.double()
-    ad, wd, bd = a.to(dev()), w.to(dev()), bias.to(dev())
-    outs = []
-    for cfg in (6, 0):
-        c = torch.empty(m, n, device=dev(), dtype=torch.bfloat16)
-        with options(gemm_cfg=cfg):
-            ok(lib.casync_op_pw_gemm(ptr(ad), k, ptr(wd), ptr(bd), ptr(c), n, m, n, k, 0, 0, 0, 0, 0, 0, 0, 0, stream()))
-        outs.append(c.cpu().double())
-        assert float(((outs[-1] - ref).abs() / (ref.abs() + 1.0)).max()) < 2 ** -8
-    assert torch.equal(outs[0], outs[1])     # no epilogue arithmetic: same fp32 sums, same rounding
-
-
 @pytest.mark.parametrize("prefix,cin,cout,stride,res,h,w", IR_CASES)
 def test_ir_fused_block_bf16(bf16_ops, recipe_sd, prefix, cin, cout, stride, res, h, w):
     """bf16 fused inverted residual (bf16 MFMA, bf16 E/D tiles) vs the fp32 oracle module on the
