@@ -32,6 +32,8 @@
 // k-steps (lane group q = l>>4 takes k = 16g+4q .. +3; A and B use the same k permutation).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "ir_common.h"
 
@@ -81,19 +83,23 @@ struct IRGeom {
   // E row pitch in floats: rows are padded by 16 B so that the tails of consecutive rows (same hx, same key) fall on
   // different banks (an unpadded row is a multiple of 64 B)
   static constexpr int EROW = IW * CC + 4;
+  static constexpr int EBUF = IH * EROW;                    // one expanded halo tile
   static constexpr int NT1 = CC / 16;
-  static constexpr int MT3 = OP / 64;                       // P3 M-tiles per wave
+  static constexpr int MT3 = OP / 64;                       // P3 M-tiles per wave = output rows per wave
   static constexpr int NT3 = COUT / 16;
   static constexpr int LDO = 36;                            // epilogue staging of the bf16 kernel: 32 columns + 4
-  // one weight buffer: W1c [CC][CIN], W2c [COUT][CC], Wd [9][CC], b1 [CC], bd [CC]
-  static constexpr int wW1 = 0, wW2 = wW1 + CC * CIN, wWd = wW2 + COUT * CC, wB = wWd + 9 * CC;
-  static constexpr int WBUF = wB + 2 * CC;
-  // LDS carve (floats)
+  // Weight chunks travel in two groups with different lead (see the kernel's schedule): W1c [CC][CIN] is read by P1
+  // one barrier interval before W2c [COUT][CC] + Wd [9][CC] + bd [CC] of the same chunk are read by P2 / P3.  (b1 does
+  // not go through LDS: a lane's four expand biases are one 16-B load, requested an interval ahead.)
+  static constexpr int W1BUF = CC * CIN;
+  static constexpr int wWd = COUT * CC, wBd = wWd + 9 * CC, W2BUF = wBd + CC;
+  // LDS carve (floats): E and both weight groups are double buffered; D never exists (P2 leaves it in the registers
+  // P3 reads as its MFMA operand)
   static constexpr int oE = 0;
-  static constexpr int oD = oE + IH * EROW;
-  static constexpr int oW = oD + OP * CC;
+  static constexpr int oW1 = oE + 2 * EBUF;
+  static constexpr int oW2 = oW1 + 2 * W1BUF;
   // stride 1 and CIN == COUT = the blocks with a residual connection (module/unet.py:14): their epilogue takes x
-  // from a copy of the tile's centre pixels parked in LDS over the dead E / D / W tiles (written from the A fragments,
+  // from a copy of the tile's centre pixels parked in LDS over the dead E / W tiles (written from the A fragments,
   // which hold exactly those values), instead of reading it from HBM a second time (it had left L2 by then:
   // PMC traffic of these kernels was 1.54 x algorithmic)
   static constexpr bool RESC = STRIDE == 1 && CIN == COUT && !UPG;
@@ -103,18 +109,17 @@ struct IRGeom {
   // pixels: its first taps span floor(9 s) + 1 = 5 rows / floor(17 s) + 1 = 9 columns (s = (n/2 - 1) / (n - 1)
   // < 1/2), plus the second tap of the last one.
   static constexpr int GH = 7, GW = 11, GBUF = GH * GW * CC;
-  static constexpr int oG = oW + 2 * WBUF;
+  static constexpr int oG = oW2 + 2 * W2BUF;
   static constexpr int NWG = (GH * GW * CC / 4 + 255) / 256;
   static constexpr int loop_total = oG + (UPG ? 2 * GBUF : 0);
   static constexpr int total = RESC && oX + OP * CIN > loop_total ? oX + OP * CIN : loop_total;
-  static_assert((IH * EROW) % 4 == 0 && (OP * CC) % 4 == 0 && WBUF % 4 == 0, "16-B aligned carve");
+  static_assert(EBUF % 4 == 0 && W1BUF % 4 == 0 && W2BUF % 4 == 0, "16-B aligned carve");
   static_assert(TAIL > 0 && TAIL <= 16, "tile walk: a partial last tile per row");
   static constexpr int KG = CIN / 16;                       // k-groups of 16: one A-fragment float4 each
-  static_assert(total * 4 <= 160 * 1024, "LDS budget");
   // per-thread register slots of one weight chunk in flight
   static constexpr int NW1 = (CC * CIN / 4 + 255) / 256;
   static constexpr int NW2 = (COUT * CC / 4 + 255) / 256;
-  static constexpr int NWD = (11 * CC / 4 + 255) / 256;    // Wd, b1, bd are contiguous per chunk in LDS
+  static constexpr int NWD = (10 * CC / 4 + 255) / 256;    // rows 0..8 = taps, 9 = bd
 };
 
 // The parked residual tile sX [OP][CIN]: its stores come from the A fragments (eight consecutive lanes = eight
@@ -141,6 +146,18 @@ constexpr int ir_min_waves() {
 // channel and the 1x1 conv per pixel, so W1 * cat(up(lo), skip) = up(W1a * lo) + W1b * skip: `lo` now holds
 // G = W1a * lo [B, H/2, W/2, ld_lo >= CE] (a plain GEMM at a quarter of the pixels), `in` / CIN are the skip half
 // alone and w1 = W1b [CE][CIN].  P1 runs over half the K and adds the interpolated G slice before the LReLU.
+//
+// Schedule (round 4): ONE workgroup barrier per chunk.  The only thing the four waves exchange is E (a depthwise tap
+// reaches into pixels another wave expanded); D does not need LDS at all -- a lane of P2 computes four consecutive
+// channels of the pixels (row 2*wave + j, column lane & 15), which is exactly the B operand P3's MFMA wants from that
+// lane (k-step s <-> channel 4q + s; the W2 fragment is read with the same k permutation).  With E double buffered a
+// barrier interval is
+//     [ stage: park W1(c+1) / W2d(c), request W1(c+2) / W2d(c+1) / G(c+1) ]  P2(c-1)  P3(c-1)  P1(c)   | barrier |
+// i.e. a wave runs depthwise -> project -> next expand without meeting anybody, 40-64 MFMAs back to back, and the
+// barrier only says "E(c) is complete".  (Round 3 had two barriers per chunk and a D round trip through LDS; its
+// waves spent 0.31-0.41 of their time in waits with the LDS conflicts already gone, profiles/r3_mfma_busy.json.)
+// The chunk loop is unrolled over the buffer parity, so every LDS address in it is a per-lane constant plus an
+// instruction immediate.
 template <typename T, int CIN, int CE, int COUT, int STRIDE, int CC, int UPS>
 __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>())) void ir_fused_kernel(
     const T* __restrict__ lo, int ld_lo, int c_lo,
@@ -152,10 +169,12 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
   using G = IRGeom<CIN, COUT, STRIDE, CC, UPG>;
   constexpr int NCH = CE / CC;
   static_assert(CC == 16, "e_off() keys and the E row padding are worked out for 64-B pixels");
+  static_assert(NCH % 2 == 0 && NCH >= 2, "the chunk loop is unrolled over the buffer parity");
   static_assert(!UPG || (STRIDE == 1 && sizeof(T) == 4), "the commuted form exists for the fp32 stride-1 Up blocks");
-  // diagnostic only (null in every product call; tools/experiments/ir_timeline.py): shader cycles wave 0 of
-  // a workgroup spends in the prologue / P1 / P2 / P3 (each including the barrier wait that ends it) / epilogue
-  unsigned long long t_mark = stamps ? __builtin_amdgcn_s_memtime() : 0, t_phase[5] = {0, 0, 0, 0, 0};
+  static_assert(G::total * 4 <= 160 * 1024, "LDS budget");
+  // diagnostic only (null in every product call; tools/experiments/ir_timeline.py): shader cycles wave 0 of a
+  // workgroup spends in the prologue / P1 / P2 / P3 / epilogue, and (slot 5) waiting at the chunk barriers
+  unsigned long long t_mark = stamps ? __builtin_amdgcn_s_memtime() : 0, t_phase[6] = {0, 0, 0, 0, 0, 0};
   auto mark = [&](int slot) {
     if (stamps) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -165,10 +184,11 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
   };
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sE = smem + G::oE;
-  float* sD = smem + G::oD;
-  float* sW = smem + G::oW;
+  float* sW1 = smem + G::oW1;
+  float* sW2 = smem + G::oW2;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the same number in a scalar register (LDS-DMA destinations)
   const int l15 = lane & 15, q = lane >> 4;
   const int b = blockIdx.z, oy0 = blockIdx.y * G::TH, ox0 = blockIdx.x * TW;
   const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
@@ -182,7 +202,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
   // 64 pieces land contiguously), a chunk ahead of their use.
   [[maybe_unused]] float* sG = smem + G::oG;
   [[maybe_unused]] int gy0 = 0, gx0 = 0;
-  [[maybe_unused]] const T* gsrc[G::NWG];
+  [[maybe_unused]] unsigned gsrc[G::NWG];   // byte offsets from `lo`
   if constexpr (UPG) {
     const int Hl = H >> 1, Wl = W >> 1;
     const float sy = (float)(Hl - 1) / (float)(H - 1), sx = (float)(Wl - 1) / (float)(W - 1);
@@ -193,77 +213,77 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
       const int idx = tid + 256 * j, p = idx / (CC / 4), c4 = (idx - p * (CC / 4)) * 4;
       const int py = p / G::GW, px = p - py * G::GW;
       const int gy = gy0 + py < Hl ? gy0 + py : Hl - 1, gx = gx0 + px < Wl ? gx0 + px : Wl - 1;
-      gsrc[j] = lo + ((size_t)(b * Hl + gy) * Wl + gx) * ld_lo + c4;
+      gsrc[j] = (unsigned)((((size_t)(b * Hl + gy) * Wl + gx) * ld_lo + c4) * sizeof(T));
     }
   }
 
-  // ---- weight chunk: global -> registers (wload) and registers -> LDS (wstore) ----
-  f32x4 rw1[G::NW1], rw2[G::NW2], rwd[G::NWD];
-  auto gload = [&](int ce0, int buf) {
+  // ---- staging: everything a chunk needs besides the A fragments goes HBM / L2 -> LDS directly (global_load_lds,
+  //      16 B per lane, a wave's 64 pieces land contiguously): no staging registers, no ds_write.  The LDS layouts are
+  //      swizzled (xs()), so the permutation is applied on the SOURCE side: LDS column s of row r receives global
+  //      column s ^ key(r) -- xs() is its own inverse within a row.  Per-thread source pointers of chunk 0: ----
+  unsigned src1[G::NW1], src2[G::NW2];   // byte offsets from w1 / w2 (+ the chunk's uniform offset)
+  const float* srcd[G::NWD];
+#pragma unroll
+  for (int j = 0; j < G::NW1; ++j) {
+    const int idx = tid + 256 * j, r = idx / (CIN / 4), sl = idx - r * (CIN / 4);
+    src1[j] = idx < CC * CIN / 4 ? 4u * xs<CIN>(r, 4 * sl) : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < G::NW2; ++j) {
+    const int idx = tid + 256 * j, r = idx / (CC / 4), sl = idx - r * (CC / 4);
+    src2[j] = idx < COUT * CC / 4 ? 4u * (r * CE + (xs<CC>(r, 4 * sl) - r * CC)) : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < G::NWD; ++j) {
+    const int idx = tid + 256 * j, t = idx / (CC / 4), c4 = (idx - t * (CC / 4)) * 4;   // t: 0..8 taps, 9 = bd
+    srcd[j] = idx < 10 * CC / 4 ? (t < 9 ? wd + (size_t)t * CE : bd) + c4 : wd;
+  }
+  // one LDS-DMA instruction: 16 B per lane from (uniform base + per-lane byte offset) to (uniform LDS base + lane * 16)
+  auto dma16 = [&](const void* sbase, unsigned off, float* dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(static_cast<const char*>(sbase) + off),
+                                     (void __attribute__((address_space(3)))*)dst_wave_base, 16, 0, 0);
+  };
+  // W1c of chunk c1 -> W1 buffer P1B; W2c / Wd / bd of chunk c2 -> W2 buffer P2B; UPG: the G slice of chunk cg -> G buffer
+  // PGB.  A chunk outside [0, NCH) is skipped.
+  auto stage_w1 = [&](int c1, auto buf_c) {
+    if (c1 >= 0 && c1 < NCH) {
+      float* wb = sW1 + decltype(buf_c)::value * G::W1BUF;
+#pragma unroll
+      for (int j = 0; j < G::NW1; ++j)
+        if (G::NW1 * 256 == CC * CIN / 4 || tid + 256 * j < CC * CIN / 4) dma16(w1 + (size_t)c1 * CC * CIN, src1[j], wb + (256 * j + 64 * wave_s) * 4);
+    }
+  };
+  auto stage_w2 = [&](int c2, auto buf_c) {
+    if (c2 >= 0 && c2 < NCH) {
+      float* wb = sW2 + decltype(buf_c)::value * G::W2BUF;
+#pragma unroll
+      for (int j = 0; j < G::NW2; ++j)
+        if (G::NW2 * 256 == COUT * CC / 4 || tid + 256 * j < COUT * CC / 4) dma16(w2 + c2 * CC, src2[j], wb + (256 * j + 64 * wave_s) * 4);
+#pragma unroll
+      for (int j = 0; j < G::NWD; ++j)
+        if (tid + 256 * j < 10 * CC / 4) dma16(srcd[j] + c2 * CC, 0u, wb + G::wWd + (256 * j + 64 * wave_s) * 4);
+    }
+  };
+  auto gload = [&](int ch, auto buf_c) {
     if constexpr (UPG) {
+      if (ch < NCH) {
 #pragma unroll
-      for (int j = 0; j < G::NWG; ++j)
-        if (tid + 256 * j < G::GBUF / 4)
-          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(gsrc[j] + ce0),
-                                           (void __attribute__((address_space(3)))*)(sG + buf * G::GBUF + (256 * j + 64 * wave) * 4),
-                                           16, 0, 0);
-    }
-  };
-  auto gwait = [&]() {   // every request of this wave has landed (its G pieces are in LDS)
-    if constexpr (UPG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-  auto wload = [&](int ce0) {
-#pragma unroll
-    for (int j = 0; j < G::NW1; ++j) {
-      const int idx = tid + 256 * j;
-      if (G::NW1 * 256 == CC * CIN / 4 || idx < CC * CIN / 4)
-        rw1[j] = *reinterpret_cast<const f32x4*>(w1 + (size_t)ce0 * CIN + idx * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < G::NW2; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < COUT * CC / 4) {
-        const int r = idx / (CC / 4), c4 = (idx - r * (CC / 4)) * 4;
-        rw2[j] = *reinterpret_cast<const f32x4*>(w2 + (size_t)r * CE + ce0 + c4);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < G::NWD; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < 11 * CC / 4) {
-        const int t = idx / (CC / 4), c4 = (idx - t * (CC / 4)) * 4;   // t: 0..8 taps, 9 = b1, 10 = bd
-        const float* src = t < 9 ? wd + (size_t)t * CE : (t == 9 ? b1 : bd);
-        rwd[j] = *reinterpret_cast<const f32x4*>(src + ce0 + c4);
+        for (int j = 0; j < G::NWG; ++j)
+          if (tid + 256 * j < G::GBUF / 4) dma16(lo + ch * CC, gsrc[j], sG + decltype(buf_c)::value * G::GBUF + (256 * j + 64 * wave_s) * 4);
       }
     }
   };
-  auto wstore = [&](int buf) {
-    float* wb = sW + buf * G::WBUF;
+  f32x4 b1c[G::NT1];   // expand biases of the chunk P1 runs next (channels 16 n + 4 q .. + 3): one 16-B load per chunk
+  auto bias_load = [&](int c1) {   // always issued (a chunk past the end re-reads the last one): the barrier counts on it
+    const float* src = b1 + (c1 < NCH ? c1 : NCH - 1) * CC + 4 * q;
 #pragma unroll
-    for (int j = 0; j < G::NW1; ++j) {
-      const int idx = tid + 256 * j;
-      if (G::NW1 * 256 == CC * CIN / 4 || idx < CC * CIN / 4) {
-        const int r = idx / (CIN / 4), c4 = (idx - r * (CIN / 4)) * 4;
-        *reinterpret_cast<f32x4*>(wb + G::wW1 + xs<CIN>(r, c4)) = rw1[j];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < G::NW2; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < COUT * CC / 4) {
-        const int r = idx / (CC / 4), c4 = (idx - r * (CC / 4)) * 4;
-        *reinterpret_cast<f32x4*>(wb + G::wW2 + xs<CC>(r, c4)) = rw2[j];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < G::NWD; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < 11 * CC / 4) *reinterpret_cast<f32x4*>(wb + G::wWd + idx * 4) = rwd[j];
-    }
+    for (int n = 0; n < G::NT1; ++n) b1c[n] = *reinterpret_cast<const f32x4*>(src + 16 * n);
   };
-
-  gload(0, 0);
-  wload(0);
+  using P0 = std::integral_constant<int, 0>;
+  using P1c = std::integral_constant<int, 1>;
+  gload(0, P0{});
+  stage_w1(0, P0{});
+  bias_load(0);
   // ---- A fragments of this wave's halo rows: HBM -> registers, once (zeros outside the image;
   //      MFMA pad rows >= HP are zero too and never stored) ----
   f32x4 fa[G::MT1][G::KG];
@@ -306,9 +326,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
         fa[i][g] = ok ? ld4(src + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
-  wstore(0);
-  gwait();
-  if (NCH > 1) wload(CC);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
   __syncthreads();
   mark(0);
 
@@ -318,9 +336,9 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
 #pragma unroll
     for (int n = 0; n < G::NT3; ++n) acc3[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // per-lane constants of the chunk loop: where this lane's halo pixels go in E (-1: MFMA pad row, never stored;
-  // the depthwise conv zero-pads E, so halo pixels outside the image are 0, not lrelu(b1)), and the three tap-column
-  // bases of its depthwise pixels
+  // per-lane constants of the chunk loop: where this lane's halo pixels go in E (-1: MFMA pad row, never stored) and
+  // whether they lie inside the image.  The depthwise conv zero-pads E, so a halo pixel outside the image must come out
+  // as 0, not lrelu(b1): border tiles (only) select at the store.
   int ewr[G::MT1][G::NT1];
   bool ein[G::MT1];
 #pragma unroll
@@ -352,129 +370,151 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
       gw[i] = f32x4{ty.l0 * tx.l0, ty.l0 * tx.l1, ty.l1 * tx.l0, ty.l1 * tx.l1};
     }
   }
-  constexpr int P2_TPP = CC / 4, P2_PPI = 256 / P2_TPP, P2_NPX = G::OP / P2_PPI;
-  static_assert(P2_PPI % TW == 0 && G::TH % P2_NPX == 0, "P2 thread map");
-  const int p2_c4 = (tid % P2_TPP) * 4, p2_px = (tid / P2_TPP) % TW, p2_py0 = ((tid / P2_TPP) / TW) * P2_NPX;
+  // P2 / P3 lane map: this lane's depthwise pixels are (row MT3 * wave + j, column l15), channels 4q .. 4q+3 of the
+  // chunk; the three tap-column bases of pixel j = 0 in E
+  constexpr int NPX = G::MT3, NROW = (NPX - 1) * STRIDE + 3;
   const float* ebk[3];
 #pragma unroll
-  for (int kx = 0; kx < 3; ++kx)
-    ebk[kx] = sE + e_off<STRIDE, CC, G::IW>(p2_py0 * STRIDE, p2_px * STRIDE + kx, p2_c4 >> 2);
+  for (int kx = 0; kx < 3; ++kx) ebk[kx] = sE + e_off<STRIDE, CC, G::IW>(NPX * wave * STRIDE, l15 * STRIDE + kx, q);
 
-#pragma unroll 1
-  for (int ch = 0; ch < NCH; ++ch) {
-    const float* wb = sW + (ch & 1) * G::WBUF;
-    // ---- P1: expand GEMM over the halo.  The weight chunk is the MFMA A operand and the pixels
-    //      the B operand (the register fragments serve either role), so D[channel][pixel]: a lane
-    //      ends up with 4 CONSECUTIVE channels (rows 4q..4q+3) of ONE pixel (column l&15) -> one
-    //      16-byte LDS write per tile and one border mask per tile.  Bias = initial accumulator. ----
-    {
-      f32x4 acc[G::MT1][G::NT1];
+  // ---- P1: expand GEMM over the halo.  The weight chunk is the MFMA A operand and the pixels
+  //      the B operand (the register fragments serve either role), so D[channel][pixel]: a lane
+  //      ends up with 4 CONSECUTIVE channels (rows 4q..4q+3) of ONE pixel (column l&15) -> one
+  //      16-byte LDS write per tile.  Bias = initial accumulator. ----
+  auto p1 = [&](auto par_c) {
+    constexpr int PAR = decltype(par_c)::value;
+    const float* wb = sW1 + PAR * G::W1BUF;
+    float* eb = sE + PAR * G::EBUF;
+    f32x4 acc[G::MT1][G::NT1];
 #pragma unroll
-      for (int n = 0; n < G::NT1; ++n) {
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(wb + G::wB + 16 * n + 4 * q);
+    for (int n = 0; n < G::NT1; ++n)
 #pragma unroll
-        for (int i = 0; i < G::MT1; ++i) acc[i][n] = bias;
-      }
+      for (int i = 0; i < G::MT1; ++i) acc[i][n] = b1c[n];
+    // the weight fragments of up to four k-groups are requested before the first MFMA (one LDS round trip per chunk)
+    constexpr int GB = G::KG <= 4 ? G::KG : 2;
 #pragma unroll
-      for (int g = 0; g < G::KG; ++g) {
-        f32x4 fb[G::NT1];
+    for (int g0 = 0; g0 < G::KG; g0 += GB) {
+      f32x4 fb[GB][G::NT1];
 #pragma unroll
-        for (int n = 0; n < G::NT1; ++n)
-          fb[n] = *reinterpret_cast<const f32x4*>(wb + G::wW1 + xs<CIN>(16 * n + l15, 16 * g + 4 * q));
+      for (int g = 0; g < GB; ++g)
+#pragma unroll
+        for (int n = 0; n < G::NT1; ++n) fb[g][n] = *reinterpret_cast<const f32x4*>(wb + xs<CIN>(16 * n + l15, 16 * (g0 + g) + 4 * q));
+#pragma unroll
+      for (int g = 0; g < GB; ++g)
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int i = 0; i < G::MT1; ++i)
 #pragma unroll
-            for (int n = 0; n < G::NT1; ++n) acc[i][n] = mfma16(fb[n][s], fa[i][g][s], acc[i][n]);
-      }
-      // Few tile slots can hold MFMA pad rows (IRGeom::slot_full).
-      {
+            for (int n = 0; n < G::NT1; ++n) acc[i][n] = mfma16(fb[g][n][s], fa[i][g0 + g][s], acc[i][n]);
+    }
+    // Few tile slots can hold MFMA pad rows (IRGeom::slot_full).
 #pragma unroll
-        for (int i = 0; i < G::MT1; ++i) {
-          if (G::slot_full(i) || ewr[i][0] >= 0) {
+    for (int i = 0; i < G::MT1; ++i) {
+      if (G::slot_full(i) || ewr[i][0] >= 0) {
 #pragma unroll
-            for (int n = 0; n < G::NT1; ++n) {
-              f32x4 v = acc[i][n];
-              if constexpr (UPG) {   // + up(G)[pixel][these four channels]: four fused multiply-adds per channel
-                const float* g0 = sG + (ch & 1) * G::GBUF + go[i] + 16 * n;
-                v += gw[i][0] * *reinterpret_cast<const f32x4*>(g0);
-                v += gw[i][1] * *reinterpret_cast<const f32x4*>(g0 + CC);
-                v += gw[i][2] * *reinterpret_cast<const f32x4*>(g0 + G::GW * CC);
-                v += gw[i][3] * *reinterpret_cast<const f32x4*>(g0 + G::GW * CC + CC);
-              }
-              *reinterpret_cast<f32x4*>(sE + ewr[i][n]) = ein[i] ? lrelu4(v) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+        for (int n = 0; n < G::NT1; ++n) {
+          f32x4 v = acc[i][n];
+          if constexpr (UPG) {   // + up(G)[pixel][these four channels]: four fused multiply-adds per channel
+            const float* g0 = sG + PAR * G::GBUF + go[i] + 16 * n;
+            v += gw[i][0] * *reinterpret_cast<const f32x4*>(g0);
+            v += gw[i][1] * *reinterpret_cast<const f32x4*>(g0 + CC);
+            v += gw[i][2] * *reinterpret_cast<const f32x4*>(g0 + G::GW * CC);
+            v += gw[i][3] * *reinterpret_cast<const f32x4*>(g0 + G::GW * CC + CC);
           }
+          v = lrelu4(v);
+          if (border) {   // workgroup-uniform and a real branch (the asm keeps it from becoming selects): interior tiles pay nothing
+            asm volatile("; border tile");
+            if (!ein[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          *reinterpret_cast<f32x4*>(eb + ewr[i][n]) = v;
         }
       }
     }
-    __syncthreads();  // E complete; every wave is done with the previous chunk's P3
-    mark(1);
-    if (ch + 1 < NCH) {
-      gload((ch + 1) * CC, (ch + 1) & 1);         // UPG: the next chunk's G slice, straight into LDS
-      wstore((ch + 1) & 1);                       // park the next chunk's weights
-      if (ch + 2 < NCH) wload((ch + 2) * CC);     // and start fetching the one after
-    }
+  };
 
-    // ---- P2: depthwise 3x3 over E -> D.  Thread = 4 channels x NPX pixels STACKED IN Y, so the
-    //      (NPX-1)*STRIDE+3 tap rows are read once and shared (12 instead of 18 E reads for two
-    //      pixels); consecutive lanes walk the 16-B columns of consecutive pixels of one tap column,
-    //      one contiguous window whatever e_off() does inside a pixel ----
-    {
-      constexpr int NPX = P2_NPX, NROW = (NPX - 1) * STRIDE + 3;
-      const int c4 = p2_c4, px = p2_px, py0 = p2_py0;
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(wb + G::wB + CC + c4);
-      f32x4 a[NPX];
+  // ---- P2 + P3 of one chunk.  P2: depthwise 3x3 over E, thread = 4 channels x NPX pixels STACKED IN Y, so the
+  //      (NPX-1)*STRIDE+3 tap rows are read once and shared; the sixteen lanes of a channel quad walk sixteen
+  //      consecutive pixels of one tap column, the four quads the four 16-B columns of those pixels: one contiguous
+  //      window whatever e_off() does inside a pixel (tools/lds_bank_model.py: conflict free).  Its result IS the B
+  //      operand of P3: acc3[OP x COUT] += D[OP x CC] x W2c^T, k-step s <-> channel 4q + s. ----
+  auto p23 = [&](auto par_c) {
+    constexpr int PAR = decltype(par_c)::value;
+    const float* wb = sW2 + PAR * G::W2BUF;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(wb + G::wBd + 4 * q);
+    f32x4 fb[G::NT3];
 #pragma unroll
-      for (int j = 0; j < NPX; ++j) a[j] = bv;
+    for (int n = 0; n < G::NT3; ++n) fb[n] = *reinterpret_cast<const f32x4*>(wb + xs<CC>(16 * n + l15, 4 * q));
+    f32x4 a[NPX];
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {   // one tap column at a time: only three weight vectors live
-        f32x4 wt[3];
+    for (int j = 0; j < NPX; ++j) a[j] = bv;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) wt[ky] = *reinterpret_cast<const f32x4*>(wb + G::wWd + (ky * 3 + kx) * CC + c4);
+    for (int kx = 0; kx < 3; ++kx) {   // one tap column at a time: only three weight vectors live
+      f32x4 wt[3];
 #pragma unroll
-        for (int r = 0; r < NROW; ++r) {
-          const f32x4 e = *reinterpret_cast<const f32x4*>(ebk[kx] + r * G::EROW);
+      for (int ky = 0; ky < 3; ++ky) wt[ky] = *reinterpret_cast<const f32x4*>(wb + G::wWd + (ky * 3 + kx) * CC + 4 * q);
 #pragma unroll
-          for (int j = 0; j < NPX; ++j) {
-            const int ky = r - j * STRIDE;
-            if (ky >= 0 && ky < 3) a[j] += e * wt[ky];
-          }
+      for (int r = 0; r < NROW; ++r) {
+        const f32x4 e = *reinterpret_cast<const f32x4*>(ebk[kx] + PAR * G::EBUF + r * G::EROW);
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) {
+          const int ky = r - j * STRIDE;
+          if (ky >= 0 && ky < 3) a[j] += e * wt[ky];
         }
       }
-#pragma unroll
-      for (int j = 0; j < NPX; ++j) {
-        *reinterpret_cast<f32x4*>(sD + xs<CC>((py0 + j) * TW + px, c4)) = lrelu4(a[j]);
-      }
     }
-    gwait();
-    __syncthreads();  // D complete (and the parked weights / the G slice are visible)
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) a[j] = lrelu4(a[j]);
     mark(2);
-
-    // ---- P3: project GEMM, acc3[OP x COUT] += D[OP x CC] x W2c^T ----
-    {
 #pragma unroll
-      for (int g = 0; g < CC / 16; ++g) {
-        f32x4 fa[G::MT3], fb[G::NT3];
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int i = 0; i < G::MT3; ++i)
-          fa[i] = *reinterpret_cast<const f32x4*>(sD + xs<CC>(16 * (wave * G::MT3 + i) + l15, 16 * g + 4 * q));
+      for (int i = 0; i < G::MT3; ++i)
 #pragma unroll
-        for (int n = 0; n < G::NT3; ++n)
-          fb[n] = *reinterpret_cast<const f32x4*>(wb + G::wW2 + xs<CC>(16 * n + l15, 16 * g + 4 * q));
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int i = 0; i < G::MT3; ++i)
-#pragma unroll
-            for (int n = 0; n < G::NT3; ++n) acc3[i][n] = mfma16(fb[n][s], fa[i][s], acc3[i][n]);   // D[cout][pixel]
-      }
-    }
-    // no barrier here: the next P1 writes E only, which nobody reads until after its barrier
+        for (int n = 0; n < G::NT3; ++n) acc3[i][n] = mfma16(fb[n][s], a[i][s], acc3[i][n]);   // D[cout][pixel]
     if (stamps) asm volatile("s_nop 0" :: "v"(acc3[0][0]));   // keep P3's MFMAs in front of the stamp
     mark(3);
+  };
+  // right behind the barrier that completed E(ch), ch of parity PAR: request what the NEXT interval reads -- W1c(ch+1)
+  // and G(ch+1) into the other buffers (P1(ch+1)), W2c / Wd / bd (ch) into this parity's (P2 / P3 (ch)) -- a whole
+  // interval of ~2 us ahead of its first use
+  auto stage = [&](int ch, auto par_c) {
+    constexpr int PAR = decltype(par_c)::value;
+    using Other = std::integral_constant<int, 1 - PAR>;
+    gload(ch + 1, Other{});      // UPG: the next chunk's G slice
+    stage_w1(ch + 1, Other{});
+    stage_w2(ch, par_c);
+  };
+  // the barrier behind P1(ch): the biases of P1(ch + 1) are requested first (P1(ch)'s are dead now; the load has the
+  // next P2 / P3 to arrive in), then every LDS-DMA request of this wave -- everything older than that load -- must have
+  // landed before the other waves may read it
+  auto barrier = [&](int ch) {
+    bias_load(ch + 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::NT1) : "memory");
+    mark(1);
+    __syncthreads();           // E(ch) complete; everything staged in this interval is visible
+    mark(5);
+  };
+  p1(P0{});
+  stage(0, P0{});
+  barrier(0);
+#pragma unroll 1
+  for (int ch = 1; ch + 1 < NCH; ch += 2) {
+    stage(ch, P1c{});
+    p23(P0{});      // chunk ch - 1 (even)
+    p1(P1c{});      // chunk ch (odd)
+    barrier(ch);
+    stage(ch + 1, P0{});
+    p23(P1c{});     // chunk ch
+    p1(P0{});       // chunk ch + 1
+    barrier(ch + 1);
   }
+  stage(NCH - 1, P1c{});
+  p23(P0{});        // chunk NCH - 2
+  p1(P1c{});        // chunk NCH - 1
+  barrier(NCH - 1);
+  p23(P1c{});       // chunk NCH - 1
+
   // ---- epilogue: + b2, LReLU (+ residual) straight from the accumulators.  A lane holds four consecutive output
   //      channels of one pixel and the sixteen pixels of an MFMA tile are one output row segment, so a store
   //      instruction writes sixteen consecutive pixels x 64 B: no LDS staging, no barrier -- a wave leaves as soon as
@@ -483,7 +523,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
   float* sX = smem + G::oX;
   if constexpr (G::RESC && sizeof(T) == 4) {
     if (res) {
-      __syncthreads();   // every wave is done with D / W, which the parked tile overlays
+      __syncthreads();   // every wave is done with E / W, which the parked tile overlays
 #pragma unroll
       for (int i = 0; i < G::MT1; ++i) {
         int hy, hx;
@@ -523,7 +563,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
     if (tid == 0) {
       const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
       if (wg < 4096)
-        for (int k = 0; k < 5; ++k) stamps[wg * 8 + k] = t_phase[k];
+        for (int k = 0; k < 6; ++k) stamps[wg * 8 + k] = t_phase[k];
     }
   }
 }

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Run ON THE GPU BOX: end-to-end A/B of engine options, alternating, three rounds of `bench.py --steps 40` each.
-#   bash tools/experiments/r3_ab_bench.sh <tag> "CASYNC_X=0 CASYNC_Y=1" "CASYNC_X=1" ...
+# Run ON THE GPU BOX: end-to-end A/B of engine options or libraries (CASYNC_LIB=calipsync_amd/lib/libcasync_base.so), alternating, three rounds of `bench.py --steps 40` each.
+#   bash tools/experiments/ab_bench.sh <tag> "CASYNC_X=0 CASYNC_Y=1" "CASYNC_X=1" ...
 R=$GRAFT_REPO_ROOT
 tag=$1; shift
-O=$R/gpurun_out/r3_$tag
+O=$R/gpurun_out/ab_$tag
 mkdir -p $O; cd $R; export TMPDIR=/tmp
 for round in 1 2 3; do
   i=0

@@ -13,6 +13,7 @@ from calipsync_amd import _lib  # noqa: E402
 lib = _lib.load()
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+RES = {"down1.ir1": 1}
 s = torch.cuda.current_stream().cuda_stream
 SHAPES = [("up4.ir0", 64, 32, 1, 160), ("up4.ir1", 32, 32, 1, 160), ("up3.ir0", 128, 32, 1, 80), ("down1.ir0", 32, 64, 2, 160),
           ("down1.ir1", 64, 64, 1, 80), ("down2.ir0", 64, 128, 2, 80)]
@@ -47,10 +48,8 @@ for name, cin, cout, stride, hw in SHAPES:
     raw = raw[raw[:, :5].sum(1) > 0]
     st = raw[:, :5].astype(np.float64)
     extra = ""
-    if (raw[:, 7] > 0).all():        # the streaming kernel sums over the steps of a run (word 7): per step
-        st = st / raw[:, 7:8]
-        w = np.median(raw[:, 5:7] / raw[:, 7:8], axis=0) / (ce // 16)
-        extra = f"  [+ barrier-1 wait {w[0]:5.0f}/chunk, barrier-2 wait {w[1]:5.0f}/chunk, not in P1 / P2]"
+    if raw[:, 5].any():              # round 4: cycles wave 0 waited at the chunk barriers (not part of any phase)
+        extra = f"  [+ barrier wait {np.median(raw[:, 5]) / (ce // 16):5.0f}/chunk]"
     med = np.median(st, axis=0)
     tot = med.sum()
     nch = ce // 16
