@@ -335,8 +335,33 @@ def main():
     net = Model(6, "hubert", precision="bf16" if args.dtype == "bf16" else "fp32").to(dev)
     if rank == 0:
         net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t_bc = time.perf_counter()
     packed = broadcast_packed_weights(net if rank == 0 else None, dev)
+    torch.cuda.synchronize(dev)
+    broadcast_ms = 1e3 * (time.perf_counter() - t_bc)   # rank 0: fold + pack + upload + the collective; others: the collective
     net.adopt_packed(packed)
+
+    # ---- N > 1: what actually ran, so the line proves itself: one identity per rank -- the device's UUID
+    #      (or PCI bus id) and the host -- all-gathered; over RCCL every rank must own a device of its own
+    comm = None
+    if world > 1:
+        props = torch.cuda.get_device_properties(dev)
+        ident = str(getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None) or dev_index)
+        idents = [None] * world
+        dist.all_gather_object(idents, (socket.gethostname(), ident))
+        comm = {"world": dist.get_world_size(), "backend": dist.get_backend(), "unique_devices": len(set(idents)),
+                "hosts": len({h for h, _ in idents}), "broadcast_ms": round(broadcast_ms, 2),
+                "broadcast_bytes": int(packed.numel() * packed.element_size()),
+                "collectives_per_step": 0}
+        if comm["backend"] == "nccl" and comm["unique_devices"] != world:
+            if rank == 0:
+                print(f"bench.py: {world} RCCL ranks but only {comm['unique_devices']} distinct devices {sorted(set(idents))}: "
+                      "refusing to report a scaling point", file=sys.stderr)
+            dist.destroy_process_group()
+            sys.exit(4)
 
     # ---- inputs: this rank's contiguous shard of the global synthetic batch, resident in HBM
     B = args.batch
@@ -519,6 +544,7 @@ def main():
                        "trunk_lanes": (trunk_lanes or lanes) if two_lane else 1,
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "backend": {"nccl": "nccl (RCCL)", "gloo": "gloo"}.get(backend, "none (single process)"),
+                       **({"rccl": comm} if comm else {}),
                        **({"rehearsal": f"{world} ranks share {n_dev} GPU(s), gloo"} if shared else {}),
                        **({"strong_scaling": strong} if strong else {})},
             **({"replay_only": "serialised replays only: value is NOT the two-lane rate"} if args.replay_only else {}),

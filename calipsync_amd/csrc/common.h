@@ -93,6 +93,8 @@ struct CasyncOptions {
   int dw_lds = 1;            // CASYNC_DW_LDS: LDS-slab depthwise kernel
   int dw_lds_bytes = 32768;  // CASYNC_DW_LDS_BYTES
   int att_nz = 0;            // CASYNC_ATT_NZ: channel split of the attention kernel (0 = by batch)
+  int kv_early = 1;          // CASYNC_KV_EARLY: the attention K/V projection GEMM runs on the audio stream beside the face encoder:
+                             //   1 = in single-lane runs (small batches), 2 = always, 0 = never (between fusion MLP and attention)
 };
 CasyncOptions& casync_default_options();      // process defaults (environment read once, thread-safe)
 const CasyncOptions& casync_opts();           // options of the call in progress on this thread

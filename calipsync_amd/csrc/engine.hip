@@ -505,6 +505,15 @@ struct Plan {
     gemm(p + ".pw2", e2, b.cexp(), p + ".pw2.w", out, ld_out, m_out, b.cout, b.cexp(), ep2);
   }
 
+  // att.kv beside the face encoder (kv_early: 1 = in single-lane runs, where the launch chain is the bound; 2 = always;
+  // with two lanes the other lane already fills the chip and the extra stream only competes: -0.5 % at B=64)
+  bool kv_in_encode = false;          // set by run_forward for all three phases of a forward alike
+  bool kv_early() const { return kv_in_encode; }
+  void kv_projection() {
+    gemm("att.kv", ar[Arena::CATA] + 512, 1024, "att.kv.w", ar[Arena::KV], kBlocks * kKV, (long long)B * 100, kBlocks * kKV, 512,
+         GemmEpilogue());
+  }
+
   // Phase 1 of Model.forward: audio encoder || face encoder down to x5 (module/unet.py:315-321).
   void encode(const float* x, const float* audio) {
     using A = Arena;
@@ -542,6 +551,11 @@ struct Plan {
       bn7.aff_t = e.W("audio_model.bn7.t");
       ir(kAudio[4], ar[A::AC6], 512, ar[A::CATA] + 512, 1024, AE1, AE2, &bn7);
     }
+    // K and V projections of the audio features for all four attention blocks in one GEMM (module/unet.py:202-203,
+    // 210, 214).  They depend on the audio branch alone, so they run HERE, on the audio stream beside the face encoder,
+    // instead of between the fusion MLP and the first attention block (one launch less on the serial chain: at B=8,
+    // the reference's own batch, 24 us of 1.26 ms).
+    if (kv_early()) kv_projection();
     if (overlap) {
       if (r.status == CASYNC_OK && hipEventRecord(ev_join, aux) != hipSuccess) r.status = CASYNC_ERR_HIP;
       r.s = main_s;
@@ -582,8 +596,7 @@ struct Plan {
       ep2.pre_scale = e.W("mlp_fusion.fc2.rs");
       gemm("mlp.fc2", ar[A::H], 1024, "mlp_fusion.fc2.w", ar[A::TX], 1024, M10, 1024, 1024, ep2);
     }
-    // K and V projections of the audio features for all four blocks in one GEMM
-    gemm("att.kv", CATA + 512, 1024, "att.kv.w", ar[A::KV], kBlocks * kKV, M10, kBlocks * kKV, 512, GemmEpilogue());
+    if (!kv_early()) kv_projection();
     // ---------------- attention blocks (module/unet.py:331-336)
     Ptr ox[4] = {ar[A::OX0], ar[A::OX1], ar[A::OX2], ar[A::OX3]};
     Ptr prev = ar[A::TX];
@@ -952,6 +965,7 @@ static int run_forward(casync_handle h, const FwdArgs& A, hipStream_t caller, st
     r.profile = serial;
     Plan p{*h, Arena(o), r, bl};
     p.lane = l;
+    p.kv_in_encode = o.kv_early >= 2 || (o.kv_early == 1 && lanes == 1);
     p.stream_k = stream_k;
     p.concurrent = concurrent;
     p.ar.bind(A.ws, A.batch, esz);

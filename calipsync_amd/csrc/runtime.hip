@@ -36,6 +36,7 @@ const OptField kFields[] = {
     {"dw_lds", &CasyncOptions::dw_lds},
     {"dw_lds_bytes", &CasyncOptions::dw_lds_bytes},
     {"att_nz", &CasyncOptions::att_nz},
+    {"kv_early", &CasyncOptions::kv_early},
 };
 
 thread_local const CasyncOptions* t_current = nullptr;

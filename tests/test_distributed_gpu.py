@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.distributed as dist
 
-from calipsync_amd import recipe
+from calipsync_amd import _lib, recipe
 from calipsync_amd.sharding import broadcast_packed_weights, shard_range
 from calipsync_amd.unet import Model
 
@@ -66,6 +66,10 @@ def test_bench_launches_its_own_ranks():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["world_size"] == 2 and r["config"]["global_batch"] == 32
     assert r["value"] > 0 and r["config"]["strong_scaling"]["global_batch"] == 64
+    # the line proves what ran: ranks, backend, distinct devices, the one broadcast
+    c = r["config"]["rccl"]
+    assert c["world"] == 2 and c["backend"] == "gloo" and c["unique_devices"] == 1 and c["hosts"] == 1   # the 1-GPU rehearsal
+    assert c["broadcast_bytes"] == 4 * _lib.load().casync_packed_total() and c["broadcast_ms"] > 0 and c["collectives_per_step"] == 0
 
 
 _SHARD_WORKER = r"""
@@ -73,7 +77,7 @@ import os, sys
 import torch
 import torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-from calipsync_amd import recipe
+from calipsync_amd import _lib, recipe
 from calipsync_amd.sharding import broadcast_packed_weights, shard_range
 from calipsync_amd.unet import Model
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
