@@ -173,8 +173,11 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
   static_assert(!UPG || (STRIDE == 1 && sizeof(T) == 4), "the commuted form exists for the fp32 stride-1 Up blocks");
   static_assert(G::total * 4 <= 160 * 1024, "LDS budget");
   // diagnostic only (null in every product call; tools/experiments/ir_timeline.py): shader cycles wave 0 of a
-  // workgroup spends in the prologue / P1 / P2 / P3 / epilogue, and (slot 5) waiting at the chunk barriers
-  unsigned long long t_mark = stamps ? __builtin_amdgcn_s_memtime() : 0, t_phase[6] = {0, 0, 0, 0, 0, 0};
+  // workgroup spends in the prologue / P1 / P2 / P3 / epilogue, (slot 5) waiting at the chunk barriers and (slot 6) between a
+  // barrier and the last of its LDS-DMA requests (1.4-1.9 k cycles per chunk: not the requests' own issue cost but their
+  // address instructions queueing behind the other waves' MFMAs -- dealing the pieces round robin to the four waves,
+  // or addressing them as buffer loads, changed nothing: profiles/r4_ir_staging_variants.txt)
+  unsigned long long t_mark = stamps ? __builtin_amdgcn_s_memtime() : 0, t_phase[7] = {0, 0, 0, 0, 0, 0, 0};
   auto mark = [&](int slot) {
     if (stamps) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -484,6 +487,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
     gload(ch + 1, Other{});      // UPG: the next chunk's G slice
     stage_w1(ch + 1, Other{});
     stage_w2(ch, par_c);
+    mark(6);
   };
   // the barrier behind P1(ch): the biases of P1(ch + 1) are requested first (P1(ch)'s are dead now; the load has the
   // next P2 / P3 to arrive in), then every LDS-DMA request of this wave -- everything older than that load -- must have
@@ -563,7 +567,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
     if (tid == 0) {
       const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
       if (wg < 4096)
-        for (int k = 0; k < 6; ++k) stamps[wg * 8 + k] = t_phase[k];
+        for (int k = 0; k < 7; ++k) stamps[wg * 8 + k] = t_phase[k];
     }
   }
 }

@@ -49,7 +49,7 @@ for name, cin, cout, stride, hw in SHAPES:
     st = raw[:, :5].astype(np.float64)
     extra = ""
     if raw[:, 5].any():              # round 4: cycles wave 0 waited at the chunk barriers (not part of any phase)
-        extra = f"  [+ barrier wait {np.median(raw[:, 5]) / (ce // 16):5.0f}/chunk]"
+        extra = f"  [+ barrier wait {np.median(raw[:, 5]) / (ce // 16):5.0f}/chunk, LDS-DMA issue {np.median(raw[:, 6]) / (ce // 16):5.0f}/chunk (inside P2 before round-4b)]"
     med = np.median(st, axis=0)
     tot = med.sum()
     nch = ce // 16
