@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
 }
 
 // =====================================================================================
-// bf16 variant (BASELINE configs[2]): same tiling and phases, but activations, E, D and the two
+// bf16 variant (BASELINE configs[2]): same tiling and phases, but activations, E and the two
 // 1x1 weight chunks are bf16 and both GEMMs run on v_mfma_f32_16x16x32_bf16 (fp32 accumulate).
 // A chunk is 32 expanded channels (= the K of one project MFMA).  With the matrix work ~16x
 // cheaper the kernel is bound by the depthwise phase (VALU + LDS) and by HBM, so E/D in bf16
@@ -597,7 +597,11 @@ struct IRGeomB {
   // one weight buffer (bytes): W1c [32][CIN] bf16, W2c [COUT][32] bf16, Wd [9][32] + b1 + bd fp32
   static constexpr int wW1 = 0, wW2 = wW1 + 32 * CIN * 2, wWd = wW2 + COUT * 64, wB = wWd + 9 * 32 * 4;
   static constexpr int WBUF = wB + 2 * 32 * 4;
-  static constexpr int oE = 0, oD = oE + G::HP * 64, oW = (oD + G::OP * 64 + 15) / 16 * 16;
+  // E [IH][IW][32] bf16: 64-B pixels -- byte for byte the geometry of the fp32 kernel's 16-channel E tile, so its layout
+  // (e_off(): rows padded by 16 B, the four 16-B columns of a pixel XOR-keyed by hx, stride 2: even / odd pixel runs)
+  // applies unchanged.  D never exists (round 4): P2 leaves it in the registers P3 reads.
+  static constexpr int EBYTES = G::IH * (G::IW * 64 + 16);
+  static constexpr int oE = 0, oW = (oE + EBYTES + 15) / 16 * 16;
   static constexpr int total = oW + 2 * WBUF;
   static_assert(G::OP * G::LDO * 4 <= total, "epilogue staging must fit in E+D+W");
   static_assert(WBUF % 16 == 0, "16-B aligned carve");
@@ -621,8 +625,7 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
   using G = typename GB::G;
   constexpr int CC = 32, NCH = CE / CC;
   extern __shared__ __attribute__((aligned(16))) char smem_b[];
-  char* sE = smem_b + GB::oE;   // [HP][32] bf16, linear
-  char* sD = smem_b + GB::oD;   // [OP][32] bf16, swizzled
+  char* sE = smem_b + GB::oE;   // [IH][IW][32] bf16, e_off() layout
   char* sW = smem_b + GB::oW;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -675,10 +678,10 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
   const bf16x8 zero8 = __builtin_bit_cast(bf16x8, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
   for (int i = 0; i < G::MT1; ++i) {
-    const int hp = 16 * (wave * G::MT1 + i) + l15;
-    const int hy = hp / G::IW, hx = hp - hy * G::IW;
+    int hy, hx;   // the fp32 kernel's halo walk: tiles never straddle a halo row (what e_off() is conflict free for)
+    const bool live = halo_px<G>(wave * G::MT1 + i, l15, hy, hx);
     const int iy = iy0 + hy, ix = ix0 + hx;
-    const bool ok = hp < G::HP && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const bool ok = live && iy >= 0 && iy < H && ix >= 0 && ix < W;
     const bf16_t* src = inb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * ld_in + 8 * q;
     if constexpr (UPS) {
       const int Hl = H >> 1, Wl = W >> 1;
@@ -726,6 +729,11 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
 #pragma unroll
     for (int n = 0; n < G::NT3; ++n) acc3[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // the three tap-column bases of this lane's first depthwise pixel (row MT3 * wave, column l15) in E
+  const char* ebk[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) ebk[kx] = sE + 4 * e_off<STRIDE, 16, G::IW>(G::MT3 * wave * STRIDE, l15 * STRIDE + kx, q);
+
 #pragma unroll 1
   for (int ch = 0; ch < NCH; ++ch) {
     const char* wb = sW + (ch & 1) * GB::WBUF;
@@ -755,21 +763,18 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
       }
 #pragma unroll
       for (int i = 0; i < G::MT1; ++i) {
-        const int hp = 16 * (wave * G::MT1 + i) + l15;     // this lane's halo pixel
-        if (hp < G::HP) {
+        int hy, hx;                                        // this lane's halo pixel
+        if (halo_px<G>(wave * G::MT1 + i, l15, hy, hx)) {
           bool inside = true;
           if (border) {
-            const int hy = hp / G::IW, hx = hp - hy * G::IW;
             const int iy = iy0 + hy, ix = ix0 + hx;
             inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
           }
 #pragma unroll
-          for (int n = 0; n < 2; ++n) {
+          for (int n = 0; n < 2; ++n) {   // channels 16 n + 4 q .. + 3 = half (q & 1) of 16-B column 2 n + (q >> 1)
             const f32x4 a = inside ? lrelu4(acc[i][n]) : f32x4{0.f, 0.f, 0.f, 0.f};
-            bf16x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (bf16_t)a[r];
-            *reinterpret_cast<bf16x4*>(sE + (hp * CC + 16 * n + 4 * q) * 2) = v;
+            *reinterpret_cast<bf16x4*>(sE + 4 * e_off<STRIDE, 16, G::IW>(hy, hx, 2 * n + (q >> 1)) + 8 * (q & 1)) =
+                __builtin_convertvector(a, bf16x4);
           }
         }
       }
@@ -780,51 +785,54 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
       if (ch + 2 < NCH) wload((ch + 2) * CC);
     }
 
-    // ---- P2: depthwise 3x3 over E -> D; thread = 8 channels (one 16-B bf16 vector) x NPX pixels ----
+    // ---- P2: depthwise 3x3 over E; thread = 8 channels (16-B column q of a pixel) x NPX pixels STACKED IN Y of column
+    //      l15, rows MT3 * wave + j -- exactly what P3's MFMA wants from this lane as its B operand (k = 8 q + j), so D
+    //      stays in registers (round 4; the tap rows of the stacked pixels are shared: 12 instead of 18 E reads) ----
+    constexpr int NPX = G::MT3, NROW = (NPX - 1) * STRIDE + 3, EROWB = G::IW * 64 + 16;
+    bf16x8 fd[NPX];
     {
-      constexpr int PPI = 64, NPX = G::OP / PPI;
-      const int c8 = (tid & 3) * 8, p0 = tid >> 2;
+      const int c8 = 8 * q;
       f32x4 a0[NPX], a1[NPX];
-      const char* e0[NPX];
 #pragma unroll
       for (int j = 0; j < NPX; ++j) {
-        const int p = p0 + PPI * j, py = p / TW, px = p - py * TW;
-        e0[j] = sE + (((py * STRIDE) * G::IW + px * STRIDE) * CC + c8) * 2;
         a0[j] = *reinterpret_cast<const f32x4*>(wf + 10 * 32 + c8);
         a1[j] = *reinterpret_cast<const f32x4*>(wf + 10 * 32 + c8 + 4);
       }
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wf + t * 32 + c8);
-        const f32x4 w1v = *reinterpret_cast<const f32x4*>(wf + t * 32 + c8 + 4);
+      for (int kx = 0; kx < 3; ++kx) {
+        f32x4 w0[3], w1v[3];
 #pragma unroll
-        for (int j = 0; j < NPX; ++j) {
-          const bf16x8 e = *reinterpret_cast<const bf16x8*>(e0[j] + ((t / 3) * G::IW + (t % 3)) * CC * 2);
-          a0[j] += f32x4{(float)e[0], (float)e[1], (float)e[2], (float)e[3]} * w0;
-          a1[j] += f32x4{(float)e[4], (float)e[5], (float)e[6], (float)e[7]} * w1v;
+        for (int ky = 0; ky < 3; ++ky) {
+          w0[ky] = *reinterpret_cast<const f32x4*>(wf + (ky * 3 + kx) * 32 + c8);
+          w1v[ky] = *reinterpret_cast<const f32x4*>(wf + (ky * 3 + kx) * 32 + c8 + 4);
+        }
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) {
+          const bf16x8 e = *reinterpret_cast<const bf16x8*>(ebk[kx] + r * EROWB);
+          const f32x4 elo = {(float)e[0], (float)e[1], (float)e[2], (float)e[3]}, ehi = {(float)e[4], (float)e[5], (float)e[6], (float)e[7]};
+#pragma unroll
+          for (int j = 0; j < NPX; ++j) {
+            const int ky = r - j * STRIDE;
+            if (ky >= 0 && ky < 3) {
+              a0[j] += elo * w0[ky];
+              a1[j] += ehi * w1v[ky];
+            }
+          }
         }
       }
 #pragma unroll
       for (int j = 0; j < NPX; ++j) {
         const f32x4 l0 = lrelu4(a0[j]), l1 = lrelu4(a1[j]);
-        bf16x8 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = (bf16_t)l0[e];
-          v[e + 4] = (bf16_t)l1[e];
-        }
-        *reinterpret_cast<bf16x8*>(sD + xsb<64>(p0 + PPI * j, c8 * 2)) = v;
+        const bf16x4 h0 = __builtin_convertvector(l0, bf16x4), h1 = __builtin_convertvector(l1, bf16x4);
+        fd[j] = bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
       }
     }
-    __syncthreads();  // D complete (and the parked weights are visible)
+    __syncthreads();  // every wave is done reading E (the next P1 overwrites it); the parked weights are visible
 
     // ---- P3: project GEMM, one 32-deep MFMA per output tile and chunk (W2c = A operand,
     //      pixels = B operand: acc3[i][n] holds channels 16n+4q..+3 of pixel 16(wave*MT3+i)+l15) ----
     {
-      bf16x8 fd[G::MT3], fb[G::NT3];
-#pragma unroll
-      for (int i = 0; i < G::MT3; ++i)
-        fd[i] = *reinterpret_cast<const bf16x8*>(sD + xsb<64>(16 * (wave * G::MT3 + i) + l15, 16 * q));
+      bf16x8 fb[G::NT3];
 #pragma unroll
       for (int n = 0; n < G::NT3; ++n)
         fb[n] = *reinterpret_cast<const bf16x8*>(wb + GB::wW2 + xsb<64>(16 * n + l15, 16 * q));
