@@ -32,6 +32,7 @@ const OptField kFields[] = {
     {"fuse_q", &CasyncOptions::fuse_q},
     {"ups_commute", &CasyncOptions::ups_commute},
     {"fuse_dw", &CasyncOptions::fuse_dw},
+    {"fuse_dw_min", &CasyncOptions::fuse_dw_min},
     {"fuse_dw_min40", &CasyncOptions::fuse_dw_min40},
     {"dw_lds", &CasyncOptions::dw_lds},
     {"dw_lds_bytes", &CasyncOptions::dw_lds_bytes},

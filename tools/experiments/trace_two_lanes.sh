@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX: kernel trace of the timed two-lane run -> concurrency profile of one forward (trace_overlap.py)
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3_trace; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4_trace; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d $O/t --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 6 --warmup 3 > $O/log 2>&1
 f=$(find $O/t -name "*kernel_trace.csv" | head -1)
