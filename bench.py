@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: f32-input MFMA == f32 vector peak (155.4 measured here,
                             # profiles/r2_mfma_clock.txt)
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
-PROFILE_TAG = "r3"          # profiles/<tag>_pmc_traffic.json, <tag>_mfma_busy.json, <tag>_*_kernel_stats_replay.csv feed
+PROFILE_TAG = "r4"          # profiles/<tag>_pmc_traffic.json, <tag>_mfma_busy.json, <tag>_*_kernel_stats_replay.csv feed
                             # roofline.traffic / mfma_busy / avg_kernel_us_rocprof -- only when their source_hash matches
 
 
@@ -465,6 +465,7 @@ def main():
                 print(f"  {r['name']:48s} {r['kernel']:38s} {r['ms']:8.3f} ms {r['flops'] / max(r['ms'], 1e-6) / 1e9:8.1f} TF "
                       f"{r['bytes'] / max(r['ms'], 1e-6) / 1e6:8.1f} GB/s", file=sys.stderr)
         dom_name, dom = max(per.items(), key=lambda kv: kv[1]["ms"])
+        dom_raw = sum(sorted(r[i]["ms_raw"] for r in runs)[reps // 2] * reps for i, row in enumerate(runs[0]) if row["kernel"] == dom_name)
         executed_flops = sum(c["flops"] for c in per.values()) / reps      # of one B-frame forward, as launched
         tf = dom["flops"] / dom["ms"] / 1e9
         gbs = dom["bytes"] / dom["ms"] / 1e6
@@ -484,6 +485,7 @@ def main():
             "launches_per_step": dom["n"] // reps,
             "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
             "share_of_step": round(dom["ms"] / sum(c["ms"] for c in per.values()), 3),
+            "avg_launch_ms_raw": round(dom_raw / dom["n"], 4),     # the event pairs as measured (both are printed)
             "measured": "HIP events around every launch (minus the calibrated cost of an empty event pair); the timed "
                         "run's own launches (same lanes, tiles, grids) serialised on one stream; "
                         f"profiles/{tag}_kernel_stats_replay.csv is rocprofv3 --kernel-trace --stats of `bench.py --replay-only`",
@@ -505,7 +507,12 @@ def main():
                 roofline["traffic_source"] = why or f"{dom_name} not in the PMC summary"
             busy, why = load_profile_json("mfma_busy" if args.dtype == "f32" else "mfma_busy_bf16_b512", src_hash)
             if busy and dom_name in busy["kernels"]:
-                roofline["mfma_busy"] = busy["kernels"][dom_name]["mfma_busy_of_kernel_time"]
+                # the matrix pipes' busy cycles over the kernel's duration in the TRACE pass at the clock the peak is quoted at
+                # (>= achieved / peak by construction); the PMC pass itself runs the kernel slower: both are printed
+                bk = busy["kernels"][dom_name]
+                roofline["mfma_busy"] = bk.get("mfma_busy_of_trace_time", bk["mfma_busy_of_kernel_time"])
+                roofline["mfma_busy_pmc_pass"] = bk["mfma_busy_of_kernel_time"]
+                roofline["pmc_pass_slowdown"] = bk.get("pmc_pass_slowdown")
                 roofline["mfma_busy_source"] = busy["source"]
             else:
                 roofline["mfma_busy"] = None

@@ -79,6 +79,43 @@ def test_round3_profiles_reproduce_the_line(bench, traffic, busy, stats):
         assert line["cpu_baseline"]["kind"] in ("port", "reference")
 
 
+R4 = [("r4_bench.json", "r4_pmc_traffic.json", "r4_mfma_busy.json", "r4_f32_b64_kernel_stats_replay"),
+      ("r4_bench_bf16_b512.json", "r4_pmc_traffic_bf16_b512.json", "r4_mfma_busy_bf16_b512.json",
+       "r4_bf16_b512_kernel_stats_replay")]
+
+
+@pytest.mark.parametrize("bench,traffic,busy,stats", R4)
+def test_round4_profiles_reproduce_the_line(bench, traffic, busy, stats):
+    """Round 4: as round 3 (one source hash over the set, replay-only statistics, HIP events within 10 % of rocprofv3), and
+    the MFMA-busy figure of the line is normalised by the TRACE pass's duration, so it cannot sit below
+    achieved / peak; the PMC pass's own normalisation and its slowdown are printed next to it."""
+    for f in (bench, traffic, busy, stats + ".csv", stats + ".meta.json"):
+        if not os.path.exists(os.path.join(PROF, f)):
+            pytest.skip(f"profiles/{f} not collected yet")
+    line = json.load(open(os.path.join(PROF, bench)))
+    roof = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "mfma_busy", "mfma_busy_pmc_pass", "pmc_pass_slowdown",
+                "avg_kernel_us_rocprof", "avg_launch_ms_raw", "source_hash"):
+        assert roof.get(key) is not None, key
+    h = roof["source_hash"]
+    t = json.load(open(os.path.join(PROF, traffic)))
+    b = json.load(open(os.path.join(PROF, busy)))
+    meta = json.load(open(os.path.join(PROF, stats + ".meta.json")))
+    assert t["source_hash"] == b["source_hash"] == meta["source_hash"] == h
+    dom = roof["kernel"]
+    assert roof["traffic"] == t["kernels"][dom]["hbm_bytes_per_launch"]
+    assert roof["mfma_busy"] == b["kernels"][dom]["mfma_busy_of_trace_time"]
+    assert roof["mfma_busy_pmc_pass"] == b["kernels"][dom]["mfma_busy_of_kernel_time"]
+    if roof["bound"] == "mfma":
+        assert roof["mfma_busy"] >= roof["frac_rocprof"] - 0.03, (roof["mfma_busy"], roof["frac_rocprof"])
+    avg_ns = {short(r["Name"]): float(r["AverageNs"]) for r in csv.DictReader(open(os.path.join(PROF, stats + ".csv")))}[dom]
+    assert abs(avg_ns / 1e6 - roof["avg_launch_ms"]) / roof["avg_launch_ms"] < 0.10
+    assert roof["avg_launch_ms_raw"] >= roof["avg_launch_ms"]
+    per_launch = roof["algorithmic_gflop_per_launch"] * 1e9 if roof["bound"] == "mfma" else roof["algorithmic_bytes_per_launch"]
+    frac = per_launch / (avg_ns * 1e-9) / (roof["peak"] * (1e12 if roof["bound"] == "mfma" else 1e9))
+    assert abs(frac - roof["frac"]) / roof["frac"] < 0.10, (frac, roof["frac"])
+
+
 def test_round3_line_carries_the_secondary_block():
     """the driver's plain `bench.py` run also reports configs[2], the frame loop and the reference's own
     B=8 shape -- next to the headline, never instead of it."""

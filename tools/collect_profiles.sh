@@ -10,7 +10,7 @@
 # counters only when the hash matches the sources of the library it runs.  Results land in gpurun_out/profiles_<tag>/
 # (copy them into profiles/ and commit).
 set -e
-tag=${1:-r3}
+tag=${1:-r4}
 dt=${2:-f32}
 R=$GRAFT_REPO_ROOT
 extra=""; sfx=""; cfg="f32_b64"; what="B=64 fp32"
@@ -35,7 +35,7 @@ rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write --output-format csv -- python3 $R/b
 echo "pmc write done"
 python3 $R/tools/pmc_to_json.py $out/pmc_fetch $out/pmc_write $dst/${tag}_pmc_traffic$sfx.json "$what" > $out/pmc_traffic.txt
 bash $R/tools/collect_pmc_busy.sh ${tag}_$dt --no-secondary $extra
-python3 $R/tools/pmc_busy_to_json.py $R/gpurun_out/pmc_busy_${tag}_$dt $dst/${tag}_mfma_busy$sfx.json > $out/mfma_busy.txt
+python3 $R/tools/pmc_busy_to_json.py $R/gpurun_out/pmc_busy_${tag}_$dt $dst/${tag}_mfma_busy$sfx.json $dst/${tag}_${cfg}_kernel_stats_replay.csv > $out/mfma_busy.txt
 # the trace CSVs are large and not needed once the stats exist
 find $out $R/gpurun_out/pmc_busy_${tag}_$dt -name "*.csv" -size +5M -delete
 # bench line + launch table LAST, so that they can quote the counters collected above (copy the JSONs into profiles/ first)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """rocprofv3 --pmc passes of tools/collect_pmc_busy.sh -> per-kernel MFMA-busy / stall / LDS figures.
 
-    python tools/pmc_busy_to_json.py <pmc_busy_dir> <out.json>
+    python tools/pmc_busy_to_json.py <pmc_busy_dir> <out.json> [<kernel_stats_replay.csv>]
 
 Per kernel (average over its launches in `bench.py --replay-only`, i.e. the timed run's own launches,
 serialised):
@@ -12,6 +12,16 @@ serialised):
   wait_any / wait_inst_any / wait_inst_lds   shares of SQ_WAVE_CYCLES (parked on s_waitcnt or a barrier /
                            issue-stalled / issue-stalled on LDS)
   lds_bank_conflict        SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+  issue shares (round 4)   SQ_INSTS_VALU (vector instructions incl. MFMA), SQ_INSTS_MFMA / SQ_INSTS_VALU_MFMA_* where the
+                           counter exists, SQ_INSTS_LDS, SQ_INSTS_SALU per launch, and valu_per_mfma = (VALU - MFMA) / MFMA
+With the rocprofv3 --kernel-trace --stats summary of the same replay (third argument): a PMC pass runs
+the kernels slower than the trace pass does, so a busy fraction normalised by the PMC pass's own cycles can sit BELOW
+achieved / peak.  Per kernel:
+  trace_us                 AverageNs of the trace pass
+  pmc_pass_slowdown        kernel_cycles / (trace_us x 2.4 GHz)          (also contains the chip's clock give-back)
+  mfma_busy_of_trace_time  SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x trace_us x 2.4 GHz): the matrix pipes' busy cycles over
+                           the time the kernel takes when it is not being counted, at the clock the peak is quoted at --
+                           by construction >= achieved / peak of the same launch
 Units per MI355X_MICROARCH.md (rocprofv3 PMC slots; SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD)."""
 import collections
 import csv
@@ -38,12 +48,34 @@ def load(d):
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"_n": max(len(v) for v in cs.values())} for k, cs in agg.items()}
 
 
+CLOCK_GHZ = 2.4     # the clock the peaks of bench.py are quoted at (MI355X_MICROARCH.md)
+
+
+def trace_avg_us(path):
+    if not path or not os.path.exists(path):
+        return {}
+    return {short(r["Name"]): float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(path))}
+
+
 def main():
     src, out_path = sys.argv[1], sys.argv[2]
+    trace = trace_avg_us(sys.argv[3] if len(sys.argv) > 3 else None)
     out = {}
     for k, c in sorted(load(src).items()):
         cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
         row = {"launches_sampled": int(c["_n"]), "kernel_cycles": round(cyc)}
+        if k in trace and cyc:
+            t_cyc = trace[k] * 1e3 * CLOCK_GHZ
+            row["trace_us"] = round(trace[k], 2)
+            row["pmc_pass_slowdown"] = round(cyc / t_cyc, 3)
+            row["mfma_busy_of_trace_time"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * t_cyc), 4)
+        insts = {n: c[n] for n in c if n.startswith("SQ_INSTS_")}
+        if insts:
+            row["insts_per_launch"] = {n[9:].lower(): round(v) for n, v in sorted(insts.items())}
+            mfma = insts.get("SQ_INSTS_MFMA") or insts.get("SQ_INSTS_VALU_MFMA_MOPS_F32") or 0.0
+            if mfma and insts.get("SQ_INSTS_VALU"):
+                row["valu_per_mfma"] = round((insts["SQ_INSTS_VALU"] - mfma) / mfma, 3) if insts["SQ_INSTS_VALU"] > mfma \
+                    else round(insts["SQ_INSTS_VALU"] / mfma, 3)
         if cyc:
             row["cu_busy"] = round(c.get("SQ_BUSY_CU_CYCLES", 0.0) / (256 * cyc), 4)
             row["mfma_busy_of_kernel_time"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * cyc), 4)
