@@ -19,10 +19,14 @@
 // (4 % padding), 16x16 = 256, 20x20 = 400 rows exactly.  The weight fragment is the MFMA A operand and the pixels the
 // B operand: a lane ends up with four consecutive channels of one pixel, one 16-B LDS store per tile.
 //
-// Epilogue: + b1, LeakyReLU -> E tile [pixel][BN] in LDS (over the dead ring; 16-B columns XOR-keyed by the pixel so the
-// stores of eight consecutive pixels spread over the banks) -> every thread owns one channel quad (its nine tap
-// weights live in registers) and walks output pixels: nine 16-B LDS reads, nine packed FMAs, LeakyReLU, one coalesced
-// 16-B store of D.
+// Epilogue (round 4): + b1, LeakyReLU -> E tile in LDS (over the dead ring) as an IMAGE with a zero column on either
+// side: rows of HW + 2 pixels.  Then every thread owns one channel quad (its nine tap weights live in registers) and one
+// output column and walks down a run of output rows: the nine taps of an output are nine ds_read_b128 at COMPILE-TIME row
+// offsets from three column pointers that advance by a constant per row -- no column tests, no per-tap address
+// arithmetic, no divisions in the loop (whole frames skip the tap row above the first / below the last image row).  Round 3's epilogue recomputed
+// (frame, y, x) of every output by two divisions, tested and addressed each tap on its own and XOR-keyed it by its pixel:
+// ~150 vector instructions per output quad, 3.0-3.3 vector instructions per MFMA over the whole kernel on the 16x16 /
+// 20x20 / 40x40 instances (profiles/r4_mfma_busy.json), on the issue slots the fp32 MFMAs need.
 #include <stdlib.h>
 
 #include "common.h"
@@ -30,23 +34,51 @@
 
 namespace {
 
+// The E image both kernels build: NR rows of WP = HW + 2 pixels (a zero column left and right of the frame) of BN floats;
+// the 16-B columns of a pixel are XOR-keyed by its column (the stores of eight consecutive pixels of one channel quad fall
+// on eight different 16-B bank groups; a reader that walks down ONE column pays the key once).  No pixel padding and no
+// zero rows: the image must not outgrow the k-tile ring it overlays -- a workgroup with a larger LDS footprint loses more
+// in the two-lane schedule than a cheaper epilogue gains (first version: 144-B pixels + zero rows, -0.5 % end to end).
+template <int HW, int BN, int NR>
+struct ETile {
+  static constexpr int WP = HW + 2, ROWF = WP * BN;
+  static constexpr size_t bytes = (size_t)NR * ROWF * sizeof(float);
+  // float offset of channel quad `cq` of the pixel in image row R, column x (-1 .. HW)
+  static __device__ __forceinline__ int at(int R, int x, int cq) { return (R * WP + x + 1) * BN + ((cq ^ ((x + 1) & 7)) << 2); }
+};
+// Output rows are cut into RS runs per frame / strip so that NQ x WO x runs work items fill the 256 threads evenly.
+constexpr int pick_runs(int per_run_items, int rows, int blocks) {
+  int best = 1;
+  double best_u = 0;
+  for (int rs = 1; rs <= 8 && rs <= rows; ++rs) {
+    const int items = per_run_items * rs * blocks, rounds = (items + 255) / 256;
+    const double u = (double)items / (256.0 * rounds);
+    if (u > best_u + 0.02) best = rs, best_u = u;
+  }
+  return best;
+}
+
 // KF = floats per k-tile row: 32 (128-B rows, gemm.hip's ring) or 16 (64-B rows: half the ring, so that the whole
 // working set of a workgroup stays near the 32 KB of the 64x64 GEMM tiles it shares the CUs with -- a workgroup that
 // fills a CU's LDS shuts the other lane's kernels out, measured -2 % end to end with 74 KB rings)
-template <int HW, int F, int BN, int KF>
+template <int HW, int F, int BN, int KF, int S = 1>
 struct FTGeom {
   static constexpr int ROWB = KF * 4, RPI = 1024 / ROWB;       // row bytes; rows one LDS-DMA instruction fills (8 / 16)
   static constexpr int P = HW * HW, M = F * P, MT = (M + 15) / 16, M_PAD = 16 * MT;
   static constexpr int NT = BN / 16, WPN = 4 / NT;             // n-tiles; waves that share an n-tile
   static constexpr int MTW = (MT + WPN - 1) / WPN;             // m-tiles per wave
   static constexpr int ROWS = M_PAD + BN, LPT = (ROWS + 4 * RPI - 1) / (4 * RPI), STAGE = LPT * 4 * RPI * ROWB;
-  static constexpr int NQ = BN / 4, PSTEP = 256 / NQ;          // channel quads; pixels a pass of the epilogue covers
-  static constexpr size_t etile = (size_t)M_PAD * BN * sizeof(float);
+  static constexpr int NQ = BN / 4;                            // channel quads
+  static constexpr int HO = (HW + 2 - 3) / S + 1;              // output rows = columns
+  using E = ETile<HW, BN, F * HW>;                             // frame f occupies image rows f HW .. + HW - 1
+  static constexpr int RS = pick_runs(NQ * HO, HO, F), RPS = (HO + RS - 1) / RS;   // runs per frame, rows per run
+  static constexpr size_t etile = E::bytes;
   static constexpr size_t lds = 2 * (size_t)STAGE > etile ? 2 * (size_t)STAGE : etile;
   static constexpr int occ = (int)(160 * 1024 / lds) >= 4 ? 4 : (int)(160 * 1024 / lds);
   static_assert(NT == 2 || NT == 4, "BN = 32 or 64");
   static_assert(KF == 16 || KF == 32, "64-B or 128-B k-tile rows");
   static_assert(lds <= 160 * 1024, "LDS budget");
+  static_assert(2 * E::ROWF * 4 < 65536, "tap row offsets are DS immediates");
 };
 
 __device__ __forceinline__ void ft_dma16(const void* base, unsigned bytes, void* lds, int voff, int soff) {
@@ -130,12 +162,49 @@ __device__ __forceinline__ void pw_dw_gemm(char* ring, const float* __restrict__
   __syncthreads();   // the ring is consumed: it becomes the E tile
 }
 
-template <int HW, int F, int BN, int KF>
-__global__ __launch_bounds__(256, (FTGeom<HW, F, BN, KF>::occ)) void pw_dw_kernel(
+// The two zero columns of the E image (x = -1 and x = HW of all NR rows), all BN / 4 quads.
+template <class E, int NR, int NQ, int HW>
+__device__ __forceinline__ void e_zero_columns(float* sE, int tid) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < NR * 2 * NQ; i += 256) {
+    const int cq = i % NQ, r2 = i / NQ, R = r2 >> 1, x = (r2 & 1) ? HW : -1;
+    *reinterpret_cast<f32x4*>(sE + E::at(R, x, cq)) = z;
+  }
+}
+
+// One work item of the depthwise epilogue: channel quad cq, output column ox, `nrows` output rows downwards from output
+// row oy0.  R0 = image row of tap row ky = 0 of the first output (may be -1 for a whole frame's first row: skipped);
+// d = the first output's place in D.  EDGE: the image holds whole frames of HW rows without zero rows -- the tap row above
+// the first and below the last image row of the frame is left out; strips carry their zero rows in the image.
+template <class E, int S, int HW, bool EDGE>
+__device__ __forceinline__ void dw_run(const float* sE, int R0, int ox, int cq, int oy0, const f32x4 (&wt)[9], f32x4 bv, float* d,
+                                       size_t d_row, int nrows) {
+  int p[3];   // float offsets into the image (integers, so that the loads stay LDS instructions with immediate row offsets)
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) p[kx] = E::at(R0, ox * S + kx - 1, cq);
+  for (int r = 0; r < nrows; ++r) {
+    f32x4 a = bv;
+    const int y0 = (oy0 + r) * S - 1;                       // frame row of tap row 0
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      if (EDGE && (y0 + ky < 0 || y0 + ky >= HW)) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) a += *reinterpret_cast<const f32x4*>(sE + p[kx] + ky * E::ROWF) * wt[ky * 3 + kx];
+    }
+    *reinterpret_cast<f32x4*>(d) = lrelu4(a);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) p[kx] += S * E::ROWF;
+    d += d_row;
+  }
+}
+
+template <int HW, int F, int BN, int KF, int S>
+__global__ __launch_bounds__(256, (FTGeom<HW, F, BN, KF, S>::occ)) void pw_dw_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W1, const float* __restrict__ b1,
     const float* __restrict__ wd, const float* __restrict__ bd, float* __restrict__ D, int ldd, int frames, int K, int N,
-    int stride, int n_ntiles, int nwg, unsigned a_bytes, unsigned w_bytes, const float* __restrict__ ups, int ld_ups) {
-  using G = FTGeom<HW, F, BN, KF>;
+    int n_ntiles, int nwg, unsigned a_bytes, unsigned w_bytes, const float* __restrict__ ups, int ld_ups) {
+  using G = FTGeom<HW, F, BN, KF, S>;
+  using E = typename G::E;
   constexpr int ROWB = G::ROWB, RPI = G::RPI, CPR = ROWB / 16;   // 16-B columns per row
   extern __shared__ __attribute__((aligned(16))) char ring[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -173,57 +242,47 @@ __global__ __launch_bounds__(256, (FTGeom<HW, F, BN, KF>::occ)) void pw_dw_kerne
   f32x4 acc[G::MTW];
   pw_dw_gemm<G, BN, KF>(ring, A, W1, a_bytes, w_bytes, voff, nk, wave, l15, q, acc);
 
-  // ---- epilogue 1: + b1, LeakyReLU -> E[pixel][BN] (16-B column XOR pixel & 7) ----
+  // ---- epilogue 1: + b1, LeakyReLU -> the zero-bordered E image ----
   float* sE = reinterpret_cast<float*>(ring);
+  e_zero_columns<E, F * HW, G::NQ, HW>(sE, tid);
   {
     const f32x4 bias = *reinterpret_cast<const f32x4*>(b1 + n0 + 16 * wn + 4 * q);
 #pragma unroll
     for (int i = 0; i < G::MTW; ++i) {
       const int t = wm + G::WPN * i;
-      if (t < G::MT) {
-        const int px = 16 * t + l15;
+      const int px = 16 * t + l15;
+      if (t < G::MT && px < m_valid) {
+        const int f = px / G::P, rem = px - f * G::P, y = rem / HW, x = rem - y * HW;
         f32x4 v = acc[i] + bias;
-        if (ups && px < m_valid) {
+        if (ups) {
           // + the bilinear x2 upsample of the low-resolution half of an Up block's expand conv (it commutes with the
           // 1x1 conv: common.h GemmEpilogue::ups_src), HW/2 x HW/2 frames of ld_ups channels
-          const int f = px / G::P, rem = px - f * G::P, y = rem / HW, x = rem - y * HW;
           v += ups_at<HW>(ups + (size_t)(f0 + f) * (HW / 2) * (HW / 2) * ld_ups + n0 + 16 * wn + 4 * q, ld_ups, y, x);
         }
-        *reinterpret_cast<f32x4*>(sE + px * BN + (((4 * wn + q) ^ (px & 7)) << 2)) = lrelu4(v);
+        *reinterpret_cast<f32x4*>(sE + E::at(f * HW + y, x, 4 * wn + q)) = lrelu4(v);
       }
     }
   }
   __syncthreads();
 
-  // ---- epilogue 2: depthwise 3x3 (zero padding), + bd, LeakyReLU -> D ----
+  // ---- epilogue 2: depthwise 3x3 (zero columns = the horizontal padding; the vertical one by skipping tap rows), + bd, LeakyReLU -> D ----
   {
-    const int cq = tid % G::NQ, p_first = tid / G::NQ;
-    const int ho = (HW + 2 - 3) / stride + 1, pout = ho * ho;
-    const float* wq = wd + n0 + 4 * cq;
+    constexpr int HO = G::HO, NITEM = G::NQ * HO * G::RS * F;
     f32x4 wt[9];
+    int cq_of = -1;
+    for (int id = tid; id < NITEM; id += 256) {
+      const int cq = id % G::NQ, rest = id / G::NQ, ox = rest % HO, run = rest / HO, f = run / G::RS, r0 = (run - f * G::RS) * G::RPS;
+      if (f >= nf) continue;
+      if (cq != cq_of) {   // (256 % NQ == 0: a thread keeps its channel quad; loaded once)
+        const float* wq = wd + n0 + 4 * cq;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(wq + (size_t)t * N);
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(bd + n0 + 4 * cq);
-    float* dq = D + (size_t)f0 * pout * ldd + n0 + 4 * cq;
-    const int total = nf * pout;
-    for (int po = p_first; po < total; po += G::PSTEP) {
-      const int f = po / pout, rem = po - f * pout;
-      const int oy = rem / ho, ox = rem - oy * ho;
-      const int iy0 = oy * stride - 1, ix0 = ox * stride - 1;
-      f32x4 a = bv;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int iy = iy0 + ky;
-        if (iy < 0 || iy >= HW) continue;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int ix = ix0 + kx;
-          if (ix < 0 || ix >= HW) continue;
-          const int px = f * G::P + iy * HW + ix;
-          a += *reinterpret_cast<const f32x4*>(sE + px * BN + ((cq ^ (px & 7)) << 2)) * wt[ky * 3 + kx];
-        }
+        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(wq + (size_t)t * N);
+        cq_of = cq;
       }
-      *reinterpret_cast<f32x4*>(dq + (size_t)po * ldd) = lrelu4(a);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bd + n0 + 4 * cq);
+      const int nrows = HO - r0 < G::RPS ? HO - r0 : G::RPS;
+      dw_run<E, S, HW, true>(sE, f * HW + r0 * S - 1, ox, cq, r0, wt, bv,
+                             D + ((size_t)(f0 + f) * HO * HO + (size_t)r0 * HO + ox) * ldd + n0 + 4 * cq, (size_t)HO * ldd, nrows);
     }
   }
 }
@@ -241,8 +300,10 @@ struct FSGeom {
   static constexpr int NT = BN / 16, WPN = 4 / NT;
   static constexpr int MTW = (MT + WPN - 1) / WPN;
   static constexpr int ROWS = M_PAD + BN, LPT = (ROWS + 4 * RPI - 1) / (4 * RPI), STAGE = LPT * 4 * RPI * ROWB;
-  static constexpr int NQ = BN / 4, PSTEP = 256 / NQ;
-  static constexpr size_t etile = (size_t)M_PAD * BN * sizeof(float);
+  static constexpr int NQ = BN / 4;
+  using E = ETile<HW, BN, RIN>;                                // image row = strip-local input row (zero rows by epilogue 1)
+  static constexpr int RS = pick_runs(NQ * HO, SR, 1), RPS = (SR + RS - 1) / RS;   // runs per strip, output rows per run
+  static constexpr size_t etile = E::bytes;
   static constexpr size_t lds = 2 * (size_t)STAGE > etile ? 2 * (size_t)STAGE : etile;
   static constexpr int occ = (int)(160 * 1024 / lds) >= 4 ? 4 : (int)(160 * 1024 / lds);
   static_assert(NT == 2 || NT == 4, "BN = 32 or 64");
@@ -292,22 +353,24 @@ __global__ __launch_bounds__(256, (FSGeom<HW, SR, STRIDE, BN, KF>::occ)) void pw
   f32x4 acc[G::MTW];
   pw_dw_gemm<G, BN, KF>(ring, A, W1, a_bytes, w_bytes, voff, nk, wave, l15, q, acc);
 
-  // ---- epilogue 1: + b1 (+ the upsampled addend), LeakyReLU -> E[pixel][BN]; rows outside the frame are zero ----
+  // ---- epilogue 1: + b1 (+ the upsampled addend), LeakyReLU -> the E image; rows outside the frame are zero ----
+  using E = typename G::E;
   float* sE = reinterpret_cast<float*>(ring);
+  e_zero_columns<E, G::RIN, G::NQ, HW>(sE, tid);
   {
     const f32x4 bias = *reinterpret_cast<const f32x4*>(b1 + n0 + 16 * wn + 4 * q);
 #pragma unroll
     for (int i = 0; i < G::MTW; ++i) {
       const int t = wm + G::WPN * i;
-      if (t < G::MT) {
-        const int px = 16 * t + l15;
+      const int px = 16 * t + l15;
+      if (t < G::MT && px < G::M) {
         const int yl = px / HW, x = px - yl * HW, y = y0 + yl;
-        const bool inside = px < G::M && y >= 0 && y < HW;
+        const bool inside = y >= 0 && y < HW;
         f32x4 v = acc[i] + bias;
         if (ups && inside) {
           v += ups_at<HW>(ups + (size_t)fr * (HW / 2) * (HW / 2) * ld_ups + n0 + 16 * wn + 4 * q, ld_ups, y, x);
         }
-        *reinterpret_cast<f32x4*>(sE + px * BN + (((4 * wn + q) ^ (px & 7)) << 2)) = inside ? lrelu4(v) : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(sE + E::at(yl, x, 4 * wn + q)) = inside ? lrelu4(v) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   }
@@ -315,30 +378,23 @@ __global__ __launch_bounds__(256, (FSGeom<HW, SR, STRIDE, BN, KF>::occ)) void pw
 
   // ---- epilogue 2: depthwise 3x3 over the strip, + bd, LeakyReLU -> D ----
   {
-    const int cq = tid % G::NQ, p_first = tid / G::NQ;
-    const float* wq = wd + n0 + 4 * cq;
+    constexpr int HO = G::HO, NITEM = G::NQ * HO * G::RS;
+    const int oy_first = st * SR, rows_out = HO - oy_first < SR ? HO - oy_first : SR;
     f32x4 wt[9];
+    int cq_of = -1;
+    for (int id = tid; id < NITEM; id += 256) {
+      const int cq = id % G::NQ, rest = id / G::NQ, ox = rest % HO, r0 = (rest / HO) * G::RPS;
+      if (r0 >= rows_out) continue;
+      if (cq != cq_of) {
+        const float* wq = wd + n0 + 4 * cq;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(wq + (size_t)t * N);
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(bd + n0 + 4 * cq);
-    const int oy_first = st * SR, rows_out = G::HO - oy_first < SR ? G::HO - oy_first : SR;
-    float* dq = D + ((size_t)fr * G::HO + oy_first) * G::HO * ldd + n0 + 4 * cq;
-    const int total = rows_out * G::HO;
-    for (int po = p_first; po < total; po += G::PSTEP) {
-      const int oyl = po / G::HO, ox = po - oyl * G::HO;
-      const int iy0 = oyl * STRIDE, ix0 = ox * STRIDE - 1;       // strip-local input row of the first tap: always inside
-      f32x4 a = bv;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int ix = ix0 + kx;
-          if (ix < 0 || ix >= HW) continue;
-          const int px = (iy0 + ky) * HW + ix;
-          a += *reinterpret_cast<const f32x4*>(sE + px * BN + ((cq ^ (px & 7)) << 2)) * wt[ky * 3 + kx];
-        }
+        for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(wq + (size_t)t * N);
+        cq_of = cq;
       }
-      *reinterpret_cast<f32x4*>(dq + (size_t)po * ldd) = lrelu4(a);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bd + n0 + 4 * cq);
+      const int nrows = rows_out - r0 < G::RPS ? rows_out - r0 : G::RPS;
+      dw_run<E, STRIDE, HW, false>(sE, r0 * STRIDE, ox, cq, 0, wt, bv,
+                                   D + (((size_t)fr * HO + oy_first + r0) * HO + ox) * ldd + n0 + 4 * cq, (size_t)HO * ldd, nrows);
     }
   }
 }
@@ -360,19 +416,19 @@ int launch_fs(const float* a, int lda, const float* w1, const float* b1, const f
   return CASYNC_OK;
 }
 
-template <int HW, int F, int BN, int KF>
+template <int HW, int F, int BN, int KF, int S>
 int launch_ft(const float* a, int lda, const float* w1, const float* b1, const float* wd, const float* bd, float* d, int ldd,
-              int frames, int k, int n, int stride, const float* ups, int ld_ups, hipStream_t stream) {
-  using G = FTGeom<HW, F, BN, KF>;
-  auto kern = pw_dw_kernel<HW, F, BN, KF>;
+              int frames, int k, int n, const float* ups, int ld_ups, hipStream_t stream) {
+  using G = FTGeom<HW, F, BN, KF, S>;
+  auto kern = pw_dw_kernel<HW, F, BN, KF, S>;
   static unsigned long long attr_once = 0;
   if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)G::lds)) return st;
   const int n_ft = (frames + F - 1) / F, n_nt = n / BN;
   const long long nwg = (long long)n_ft * n_nt;
   const unsigned long long ab = ((unsigned long long)((long long)frames * G::P - 1) * lda + k) * 4, wb = (unsigned long long)n * k * 4;
   CASYNC_REQUIRE(nwg < (1ll << 31) && ab < (1ull << 31) && wb < (1ull << 31), "pw_dw: operand larger than 2 GiB");
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), G::lds, stream, a, lda, w1, b1, wd, bd, d, ldd, frames, k, n, stride,
-                     n_nt, (int)nwg, (unsigned)ab, (unsigned)wb, ups, ld_ups);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), G::lds, stream, a, lda, w1, b1, wd, bd, d, ldd, frames, k, n, n_nt,
+                     (int)nwg, (unsigned)ab, (unsigned)wb, ups, ld_ups);
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }
@@ -390,7 +446,7 @@ const char* pw_dw_kernel_name(int hw, int cexp, int frames, int stride) {
   (void)cexp;
   (void)frames;
   if (hw == 40) snprintf(buf, sizeof(buf), "pw_dw_strip_kernel<40, %d, %d, 32, 16>", stride == 1 ? 8 : 4, stride);
-  else snprintf(buf, sizeof(buf), "pw_dw_kernel<%d, %d, 32, 16>", hw, hw == 10 ? 2 : 1);
+  else snprintf(buf, sizeof(buf), "pw_dw_kernel<%d, %d, 32, 16, %d>", hw, hw == 10 ? 2 : 1, stride);
   return buf;
 }
 
@@ -412,7 +468,8 @@ int launch_pw_dw(const void* a, int lda, const void* w1, const float* b1, const 
   if (hw == 40)   // strips of 8 (stride 2: 4) output rows: 57 KB of LDS (10 / 5 rows: 65 KB, measured equal)
     return stride == 1 ? launch_fs<40, 8, 1, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream)
                        : launch_fs<40, 4, 2, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);
-  if (hw == 10) return launch_ft<10, 2, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, uf, ld_ups, stream);
-  if (hw == 16) return launch_ft<16, 1, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, uf, ld_ups, stream);
-  return launch_ft<20, 1, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stride, uf, ld_ups, stream);
+  if (hw == 10) return launch_ft<10, 2, 32, 16, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);
+  if (hw == 16) return launch_ft<16, 1, 32, 16, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);
+  return stride == 1 ? launch_ft<20, 1, 32, 16, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream)
+                     : launch_ft<20, 1, 32, 16, 2>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);
 }
