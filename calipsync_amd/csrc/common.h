@@ -88,7 +88,8 @@ struct CasyncOptions {
                              //   the fused kernel (up3.0 / up4.0); 0 = upsample first, as the reference writes it
   int fuse_dw = 2;           // CASYNC_FUSE_DW: expand GEMM + depthwise 3x3 in one kernel (pw_dw.hip), fp32: 1 = the 10x10 / 16x16 /
                              //   20x20 blocks (whole-frame tiles), 2 = also the 40x40 blocks (row strips)
-  int fuse_dw_min = 16;      // CASYNC_FUSE_DW_MIN: frames per launch from which the whole-frame tiles (10x10 / 16x16 / 20x20) are used
+  int fuse_dw_min = 12;      // CASYNC_FUSE_DW_MIN: frames per launch from which the whole-frame tiles (10x10 / 16x16 / 20x20) are used
+                             //   (round 4, column-walking epilogue: B=12 1.609 -> 1.584 ms with them, B=8 1.261 -> 1.275 ms)
   int fuse_dw_min40 = 8;     // CASYNC_FUSE_DW_MIN40: frames per launch from which the 40x40 strips are used (5 strips per frame:
                              //   B=8 1.312 -> 1.296 ms, B=1 0.841 -> 0.848 ms)
   int dw_lds = 1;            // CASYNC_DW_LDS: LDS-slab depthwise kernel

@@ -469,7 +469,7 @@ struct Plan {
       r.status = CASYNC_ERR_STATE;
       return;
     }
-    // (from 16 frames per launch: below that its whole-frame tiles are too few to fill the chip -- B=1 0.92 vs 0.82 ms)
+    // (from fuse_dw_min = 12 frames per launch: below that its whole-frame tiles are too few to fill the chip -- B=1 0.92 vs 0.82 ms)
     if (dt() == DT_F32 && o.fuse_dw && (b.hw_in < 40 || o.fuse_dw >= 2) && B >= (b.hw_in == 40 ? o.fuse_dw_min40 : o.fuse_dw_min) &&
         pw_dw_supported(b.hw_in, k_in, b.cexp(), b.stride)) {
       // expand GEMM whose output tile is whole frames: the depthwise conv runs on the tile in LDS, E never exists

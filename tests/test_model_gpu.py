@@ -288,7 +288,7 @@ def test_full_size_batch_properties(recipe_sd, precision):
         single = m(x[i:i + 1].contiguous(), a[i:i + 1].contiguous())
         assert (single[0] - out[i]).abs().max() < tol, i
     # bit for bit: plain GEMM tiles (the stream-K k-split depends on the row count) and the same kernels at every batch
-    # size (the fused expand+depthwise kernel is only used from 16 frames per launch up)
+    # size (the fused expand+depthwise kernel is only used from 12 frames per launch up)
     m.set_option("gemm_streamk", 0)
     m.set_option("fuse_dw", 0)
     out = m(x, a)
