@@ -420,10 +420,10 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
           f32x4 v = acc[i][n];
           if constexpr (UPG) {   // + up(G)[pixel][these four channels]: four fused multiply-adds per channel
             const float* g0 = sG + PAR * G::GBUF + go[i] + 16 * n;
-            v = fma4b(gw[i][0], *reinterpret_cast<const f32x4*>(g0), v);
-            v = fma4b(gw[i][1], *reinterpret_cast<const f32x4*>(g0 + CC), v);
-            v = fma4b(gw[i][2], *reinterpret_cast<const f32x4*>(g0 + G::GW * CC), v);
-            v = fma4b(gw[i][3], *reinterpret_cast<const f32x4*>(g0 + G::GW * CC + CC), v);
+            v += gw[i][0] * *reinterpret_cast<const f32x4*>(g0);
+            v += gw[i][1] * *reinterpret_cast<const f32x4*>(g0 + CC);
+            v += gw[i][2] * *reinterpret_cast<const f32x4*>(g0 + G::GW * CC);
+            v += gw[i][3] * *reinterpret_cast<const f32x4*>(g0 + G::GW * CC + CC);
           }
           v = lrelu4(v);
           if (border) {   // workgroup-uniform and a real branch (the asm keeps it from becoming selects): interior tiles pay nothing
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
           const int ky = r - j * STRIDE;
-          if (ky >= 0 && ky < 3) a[j] = fma4s(e, wt[ky], a[j]);
+          if (ky >= 0 && ky < 3) a[j] += e * wt[ky];
         }
       }
     }
