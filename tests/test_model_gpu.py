@@ -175,6 +175,20 @@ def test_lanes_and_stream_overlap_do_not_change_bits(net):
             assert torch.equal(net(xt, at), base), (lanes, trunk, overlap)
 
 
+def test_kv_projection_placement_does_not_change_bits(net):
+    """`kv_early`: the attention K/V projection GEMM runs either beside the face encoder on the audio stream (default in single-lane
+    runs) or between the fusion MLP and the first attention block (module/unet.py:202-203 are independent of the face branch).
+    Scheduling only: same bits in single-lane and two-lane runs."""
+    for batch in (5, 40):
+        x, a = recipe.make_inputs(batch)
+        xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
+        with options(net, kv_early=0):
+            base = net(xt, at)
+        for mode in (1, 2):
+            with options(net, kv_early=mode):
+                assert torch.equal(net(xt, at), base), (batch, mode)
+
+
 def test_fused_query_projection_matches_the_two_gemm_form(net):
     """q = query_conv(p_1(x)) as 64 extra columns of the p_1 GEMM (weights composed on the host in
     float64) vs the reference's own two GEMMs: same output to fp32 rounding."""
