@@ -11,7 +11,7 @@
 // at small batches (<= 24 frames), nz = 1 avoids the 4x Q/K re-reads once B x 4 workgroups are plenty.
 // Each V chunk is fetched into registers ahead of time (the first at kernel entry, the next under
 // the previous chunk's PV) and parked in LDS over the dead K tile, so its HBM/L2 latency hides.  QK^T and PV run on
-// v_mfma_f32_32x32x2_f32; the row softmax is a 64-lane shuffle reduction (two keys per lane).
+// v_mfma_f32_32x32x2_f32; the row softmax keeps a row on eight lanes (16 keys each) and reduces them by DPP.
 #include "common.h"
 
 namespace {
@@ -22,15 +22,22 @@ constexpr int CV = 512;   // value channels
 constexpr int QLD = 68;   // LDS row strides (floats): 16-B aligned, b128 reads conflict-free
 constexpr int SLD = 132;
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+// Value of lane (l ^ 1), (l ^ 2) and (l ^ 7 within its group of eight) by DPP (no LDS round trip): the reduction over the
+// eight lanes that share a softmax row.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141;   // quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror
+__device__ __forceinline__ float row8_max(float v) {
+  v = fmaxf(v, dpp_f<DPP_XOR1>(v));
+  v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+  return fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+}
+__device__ __forceinline__ float row8_sum(float v) {
+  v += dpp_f<DPP_XOR1>(v);
+  v += dpp_f<DPP_XOR2>(v);
+  return v + dpp_f<DPP_HALF_MIRROR>(v);
 }
 
 // LDS carve (floats): Q block, score tile, then K (QK^T phase) / V chunk (PV phase) share one area
@@ -120,23 +127,42 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(
       if (idx < NP * 32) *reinterpret_cast<f32x4*>(Vs + (idx >> 5) * VLD + (idx & 31) * 4) = vreg[j];
     }
     if (ci == 0) {
-      // ---- row softmax: wave w owns rows 8w .. 8w+7 ----
+      // ---- row softmax: wave w owns rows 8w .. 8w+7, EIGHT LANES PER ROW: lane (row l>>3, slice s = l&7) holds keys
+      //      4s + 32j + e (j, e < 4; four conflict-free 16-B reads), reduces its 16 values locally and the eight partial
+      //      results with three DPP moves (quad xor 1, xor 2, half-row mirror).  (Round 4: one row per wave pass cost 12
+      //      dependent ds_bpermute round trips per row, 96 per wave.) ----
+      float* srow = Ss + (wave * 8 + (lane >> 3)) * SLD + 4 * (lane & 7);
+      f32x4 x[4];
 #pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        float* srow = Ss + (wave * 8 + rr) * SLD;
-        const bool has2 = lane + 64 < NP;
-        const float e0 = srow[lane];
-        const float e1 = has2 ? srow[lane + 64] : -INFINITY;
-        const float mx = wave_max(fmaxf(e0, e1));
-        const float p0 = expf(e0 - mx);
-        const float p1 = has2 ? expf(e1 - mx) : 0.f;
-        const float inv = 1.f / wave_sum(p0 + p1);
-        srow[lane] = p0 * inv;
-        srow[lane + 64] = p1 * inv;  // keys 100..127 become exact zeros
-      }
+      for (int j = 0; j < 4; ++j) x[j] = *reinterpret_cast<const f32x4*>(srow + 32 * j);
+      if ((lane & 7) != 0) x[3] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};   // keys 100..127 do not exist
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, x[j][e]);
+      mx = row8_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          x[j][e] = expf(x[j][e] - mx);   // exp(-inf) = 0: the missing keys become exact zeros (PV reads them)
+          sum += x[j][e];
+        }
+      const float inv = 1.f / row8_sum(sum);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(srow + 32 * j) = x[j] * inv;
     }
     __syncthreads();
     if (ci + 1 < cpw) vfetch(cz + 1);   // next chunk's V travels under this chunk's PV
+    const int c = cz * 128 + wave * 32 + r32;
+    float rres[16];                     // ... and so do the residual values of this chunk's outputs
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      rres[r] = qi < NP ? (float)res[(row0 + qi) * ld_res + c] : 0.f;
+    }
 
     // ---- out = P V: wave w owns channels 32w .. 32w+31 of the 128-channel chunk ----
     f32x16 acc;
@@ -154,11 +180,10 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], vb[key * VLD], acc, 0, 0, 0);
       }
     }
-    const int c = cz * 128 + wave * 32 + r32;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (qi < NP) out[(row0 + qi) * ld_out + c] = (T)(gam * acc[r] + (float)res[(row0 + qi) * ld_res + c]);
+      if (qi < NP) out[(row0 + qi) * ld_out + c] = (T)(gam * acc[r] + rres[r]);
     }
     if (ci + 1 < cpw) __syncthreads();   // everyone is done with Vs before the next chunk is parked
   }
