@@ -759,8 +759,8 @@ int casync_set_option(casync_handle h, const char* name, int value) {
   int* slot = nullptr;
   const int st = casync_option_ref(h ? h->opt : casync_default_options(), name, &slot);
   if (st != CASYNC_OK) return st;
-  if (!strcmp(name, "gemm_cfg") && value >= 4) {
-    casync_set_error("option gemm_cfg=%d: tile configurations are 0..3 (-1 = cost model)", value);
+  if (!strcmp(name, "gemm_cfg") && value >= 5) {
+    casync_set_error("option gemm_cfg=%d: tile configurations are 0..4 (-1 = cost model)", value);
     return CASYNC_ERR_ARG;
   }
   *slot = value;

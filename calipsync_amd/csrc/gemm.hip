@@ -369,7 +369,15 @@ template <typename T, int BM, int BN, int WM, int WN, int NST, bool CONV, bool E
 __device__ __forceinline__ void glds_body(const T* __restrict__ A, int lda, const T* __restrict__ W, T* __restrict__ C,
                                           int ldc, int M, int N, int K, int n_ntiles, int nwg, int dp_tiles, int sk_wgs,
                                           int sk_per, const GemmEpilogue& epi) {
-  static_assert(WM * WN == 4, "4 waves");
+  // WM x WN waves tile the output; with two of them (the 64x32 tile of small-M launches) the other factor of two splits
+  // the K of every k-tile: waves 0..1 take its first two 32-B column pairs, waves 2..3 the last two, and the epilogue
+  // adds the halves in LDS.  A launch with M = 800 rows (B = 8 at 10x10) has 100-200 64x64 tiles for 256 CUs and one
+  // workgroup per CU, so nothing hides the ~0.45 us an LDS-DMA k-tile takes to arrive behind a two-stage ring: every
+  // tile shape ran at 0.45 us per k-iteration (tools/experiments/small_m_gemm.sh).  Half-size tiles fill the chip and
+  // a four-stage ring keeps three k-tiles in flight.
+  static_assert(WM * WN == 4 || WM * WN == 2, "4 waves");
+  constexpr int WK = 4 / (WM * WN);
+  static_assert(WK == 1 || (NST >= 3 && !CONV && !EUPS && sizeof(T) == 4), "the K split exists in the fp32 multi-stage loop only");
   constexpr int BK = ROWB / (int)sizeof(T);
   constexpr int E16 = 16 / (int)sizeof(T);
   constexpr int ROWS = BM + BN;
@@ -383,7 +391,8 @@ __device__ __forceinline__ void glds_body(const T* __restrict__ A, int lda, cons
   float* Cs = reinterpret_cast<float*>(ring);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave - wm * WN;
+  const int wk = wave / (WM * WN), wmn = wave - wk * (WM * WN);
+  const int wm = wmn / WN, wn = wmn - wm * WN;
   const int r32 = lane & 31, kh = lane >> 5;
   const int nk = K / BK;
   const int lrow8 = lane >> 3, lcol = lane & 7;
@@ -523,7 +532,8 @@ __device__ __forceinline__ void glds_body(const T* __restrict__ A, int lda, cons
       if (cnt >= AHEAD) wait_vmcnt<(NST - 3) * LPT>(); else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      frag(ring, 0, fa0, fb0);
+      const int g0 = WK == 1 ? 0 : 2 * wk;   // K split: this wave's column pairs are g0, g0 + 1
+      frag(ring, g0, fa0, fb0);
       // straight-line body (no branches: MORE / NEXT are compile-time), so the scheduler hints below hold
       // and the waitcnt pass sees one basic block per k-tile
       constexpr int NM = TM * TN * (sizeof(T) == 4 ? 4 : 1);   // MFMAs per column pair
@@ -536,6 +546,15 @@ __device__ __forceinline__ void glds_body(const T* __restrict__ A, int lda, cons
         asm volatile("" ::: "memory");
         const char* st = ring + (kt % NST) * STAGE;
         const char* st_next = ring + ((kt + 1) % NST) * STAGE;
+        if constexpr (WK == 2) {
+          frag(st, g0 + 1, fa1, fb1);
+          if constexpr (MORE) issue_part(kt + AHEAD, 0), issue_part(kt + AHEAD, 1);
+          mma(fa0, fb0);
+          if constexpr (NEXT) frag(st_next, g0, fa0, fb0);
+          if constexpr (MORE) issue_part(kt + AHEAD, 2), issue_part(kt + AHEAD, 3);
+          mma(fa1, fb1);
+          return;
+        }
         frag(st, 1, fa1, fb1);
         if constexpr (MORE) issue_part(kt + AHEAD, 0);
         mma(fa0, fb0);
@@ -686,7 +705,7 @@ __device__ __forceinline__ void glds_body(const T* __restrict__ A, int lda, cons
   auto epilogue = [&] {
 #pragma unroll
     for (int h = 0; h < WM; ++h) {
-      if (wm == h) {
+      if (wm == h && wk == 0) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -697,6 +716,19 @@ __device__ __forceinline__ void glds_body(const T* __restrict__ A, int lda, cons
           }
       }
       __syncthreads();
+      if constexpr (WK == 2) {   // the other half of K
+        if (wm == h && wk == 1) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              float* cbase = Cs + (i * 32 + 4 * kh) * LDC_S + wn * (BN / WN) + j * 32 + r32;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) cbase[((r & 3) + 8 * (r >> 2)) * LDC_S] += acc[i][j][r];
+            }
+        }
+        __syncthreads();
+      }
       epilogue_rows<T, 256, BM / WM, BN, 4, false, EUPS>(Cs, m0 + h * (BM / WM), n0, M, C, ldc, epi, tid);
       __syncthreads();   // staging consumed before the next block / the next loads overwrite the ring
     }
@@ -822,7 +854,7 @@ int launch_glds_t(const T* a, int lda, const T* w, T* c, int ldc, int m, int n, 
   CASYNC_REQUIRE(nwg < (1ll << 31), "gemm grid too large");
   constexpr int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds);
   const long long cap = 256ll * per_cu;
-  const StreamKSplit sk = stream_k_split(nwg, k / (ROWB / (int)sizeof(T)), BM * BN, epi.sk_ws != nullptr && use_sk);
+  const StreamKSplit sk = stream_k_split(nwg, k / (ROWB / (int)sizeof(T)), BM * BN, epi.sk_ws != nullptr && use_sk && WM * WN == 4);
   const long long want = sk.dp_tiles + sk.wgs;
   const unsigned grid = (unsigned)(want > cap ? cap : want);
   GemmEpilogue e2 = epi;
@@ -901,23 +933,24 @@ int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, i
 // Tile choice.  On a 256-CU chip a launch of G workgroups finishes after ceil(G/256) "rounds" of
 // one tile per CU (co-resident tiles share the CU's matrix pipes, so they add, not overlap);
 // pick the tile that minimises rounds x tile area, preferring the larger tile on ties.
-enum Cfg { C128x128 = 0, C128x64, C64x64, C128x32, CFG_COUNT };
+enum Cfg { C128x128 = 0, C128x64, C64x64, C128x32, C64x32, CFG_COUNT };
 
 struct TileCfg { Cfg id; int bm, bn; };
-constexpr TileCfg kTiles[] = {{C128x128, 128, 128}, {C128x64, 128, 64}, {C64x64, 64, 64}, {C128x32, 128, 32}};
+constexpr TileCfg kTiles[] = {{C128x128, 128, 128}, {C128x64, 128, 64}, {C64x64, 64, 64}, {C128x32, 128, 32}, {C64x32, 64, 32}};
 
 // does launch_cfg() send this config to the LDS-DMA ring kernel?
 bool takes_ring(const TileCfg& t, long long tiles, int dtype) {
+  if (t.id == C64x32) return dtype == DT_F32 && glds_mode() >= 2;   // fp32 only (see pick_cfg)
   return (t.id == C128x128 || t.id == C128x64 || t.id == C64x64) &&
          (t.bm + t.bn < 256 || tiles <= 256) &&
          ((dtype == DT_BF16 && glds_mode() >= 1) || (dtype == DT_F32 && glds_mode() >= 2));
 }
 
-int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullptr, bool concurrent = false) {
+int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullptr, bool concurrent = false, bool small_m_ok = true) {
   const int forced = casync_opts().gemm_cfg;
   const int nk = k / (ROWB / dtype_size(dtype));
   if (use_sk) *use_sk = false;
-  if (forced >= 0 && forced < CFG_COUNT && n % kTiles[forced].bn == 0) {
+  if (forced >= 0 && forced < CFG_COUNT && n % kTiles[forced].bn == 0 && (forced != C64x32 || dtype == DT_F32)) {
     const TileCfg& t = kTiles[forced];
     const long long g = (long long)((m + t.bm - 1) / t.bm) * (n / t.bn);
     if (use_sk) *use_sk = takes_ring(t, g, dtype) && stream_k_split(g, nk, t.bm * t.bn, stream_k).wgs > 0;
@@ -934,10 +967,19 @@ int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullp
   const int conc_mode = casync_opts().gemm_conc;
   const int conc_tiles = dtype == DT_BF16 && casync_opts().gemm_conc_tiles > 2048 ? 2048 : casync_opts().gemm_conc_tiles;
   const long long t64 = (long long)((m + 63) / 64) * (n / 64);
+  // Launches that do not give a 64x64 grid one tile per CU (M = 100..800 rows: B = 1..8 at 10x10): the 64x32 tile with
+  // the K split inside the workgroup and a four-stage ring.  Single-lane plan, fp32 only (its epilogue's thread map).
+  // Measured against 64x64 + stream-K (tools/experiments/small_m_gemm.sh, us per launch): (800,576,1024) 14 / 17,
+  // (800,1024,512) 14 / 16, (800,512,1024) 14 / 16, (800,512,256) 7 / 9, (100,1024,1024) 14 / 14.5; from 208 tiles with
+  // 32 k-tiles on it loses: (800,1024,1024) 24 / 23, (800,2048,1024) 42 / 34.  A six-stage ring is slower than four.
+  if (small_m_ok && !concurrent && dtype == DT_F32 && glds_mode() >= 2 && casync_opts().gemm_small_m && n % 32 == 0 &&
+      (t64 <= 128 || (t64 <= 256 && nk <= 16)))
+    return C64x32;
   int best = -1;
   double best_cost = 0;
   for (const TileCfg& t : kTiles) {
     if (n % t.bn) continue;
+    if (t.id == C64x32) continue;   // chosen by the rule above only
     if (concurrent && n % 64 == 0) {
       if (conc_mode == 1 && t.id != C64x64) continue;
       if (conc_mode == 2 && t.id == C128x128) continue;
@@ -974,12 +1016,13 @@ const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype, b
     case C128x128: cfg = "128, 128, 2, 2"; break;
     case C128x64: cfg = "128, 64, 2, 2"; break;
     case C64x64: cfg = "64, 64, 2, 2"; break;
+    case C64x32: cfg = "64, 32, 2, 1"; break;   // four stages, see the snprintf below
     default: cfg = "128, 32, 4, 1"; break;
   }
   const TileCfg& tc = kTiles[id];
   const long long tiles = (long long)((m + tc.bm - 1) / tc.bm) * (n / tc.bn);
   if (takes_ring(tc, tiles, dtype))
-    snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, %d, false>", t, cfg, tc.bm + tc.bn >= 256 ? 3 : 2);
+    snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, %d, false>", t, cfg, id == C64x32 ? 4 : (tc.bm + tc.bn >= 256 ? 3 : 2));
   else
     snprintf(buf, sizeof(buf), "pw_gemm_kernel<%s, %s>", t, cfg);
   return buf;
@@ -1017,6 +1060,13 @@ int launch_pw_gemm(const void* a, int lda, const void* w, void* c, int ldc, int 
     case C128x128: return launch_cfg<128, 128, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
     case C128x64: return launch_cfg<128, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
     case C64x64: return launch_cfg<64, 64, 2, 2>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
+    case C64x32: {
+      const bool fits32 = ((size_t)(m - 1) * lda + k) * 4 < (1ull << 31) && (size_t)n * k * 4 < (1ull << 31);
+      CASYNC_REQUIRE(dtype == DT_F32, "pw_gemm: the 64x32 tile is fp32 only");
+      if (!fits32) return launch_cfg<128, 32, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, false);   // pointer-addressed kernel
+      return launch_glds_t<float, 64, 32, 2, 1, 4>(static_cast<const float*>(a), lda, static_cast<const float*>(w),
+                                                   static_cast<float*>(c), ldc, m, n, k, epi, stream, false);
+    }
     default: return launch_cfg<128, 32, 4, 1>(a, lda, w, c, ldc, m, n, k, epi, stream, dtype, sk);
   }
 }
@@ -1027,9 +1077,9 @@ template <typename T>
 int launch_conv_t(const T* in, const T* w, T* out, int ldc, int m, int n, int k, const GemmEpilogue& epi,
                   hipStream_t stream, int dtype) {
   bool sk = false;
-  const int cfg = pick_cfg(m, n, k, epi.sk_ws != nullptr, dtype, &sk, epi.concurrent != 0);
+  const int cfg = pick_cfg(m, n, k, epi.sk_ws != nullptr, dtype, &sk, epi.concurrent != 0, false);
   // the ring kernel's two 48-KB-class tiles; the A "leading dimension" is unused (rows are gathered)
-  const bool small = cfg == C64x64 || n % 64 || m <= 4096;
+  const bool small = cfg == C64x64 || cfg == C64x32 || n % 64 || m <= 4096;
   return small ? launch_glds_t<T, 64, 64, 2, 2, 2, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C64x64)
                : launch_glds_t<T, 128, 64, 2, 2, 2, true>(in, 0, w, out, ldc, m, n, k, epi, stream, sk && cfg == C128x64);
 }
@@ -1040,8 +1090,8 @@ const char* conv3x3_gemm_kernel_name(int batch, int h, int wdt, int cin, int cou
   static thread_local char buf[64];
   const int ho = (h + 2 * pad - 3) / stride + 1, wo = (wdt + 2 * pad - 3) / stride + 1;
   const int m = batch * ho * wo;
-  const int cfg = pick_cfg(m, cout, 9 * cin, stream_k, dtype, nullptr, concurrent);   // the launch's own choice
-  const bool small = cfg == C64x64 || cout % 64 || m <= 4096;
+  const int cfg = pick_cfg(m, cout, 9 * cin, stream_k, dtype, nullptr, concurrent, false);   // the launch's own choice
+  const bool small = cfg == C64x64 || cfg == C64x32 || cout % 64 || m <= 4096;
   snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, 2, 2, %d, true>", dtype == DT_BF16 ? "__bf16" : "float",
              small ? "64, 64" : "128, 64", 2);
   return buf;

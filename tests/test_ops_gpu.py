@@ -82,6 +82,35 @@ def test_pw_gemm_stream_k_random_shapes_match_plain_tiles(lib):
     assert worst < 5e-6, worst
 
 
+@pytest.mark.parametrize("m,n,k", [(800, 576, 1024), (800, 1024, 512), (100, 2304, 512), (1, 32, 32), (65, 96, 64),
+                                   (3200, 256, 1024), (777, 160, 96), (8, 1024, 1024)])
+def test_pw_gemm_small_m_tile_with_k_split_in_the_workgroup(lib, m, n, k):
+    """The 64x32 tile of the small-batch plan (gemm_cfg=4): two wave pairs take the two halves of every k-tile and the
+    epilogue adds them in LDS.  Forced here over ragged M, N that is only a multiple of 32, an odd number of k-tiles,
+    with the whole epilogue (scaled pre-residual, activation, post-residual, affine, accumulator in/out); the result
+    repeats bit for bit and, as the cost model's own choice, equals the forced one."""
+    g = torch.Generator().manual_seed(m * 13 + n + k)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    bias, ps, s2, t2 = (torch.randn(n, generator=g) for _ in range(4))
+    pre, post = torch.randn(m, n, generator=g), torch.randn(m, n, generator=g)
+    v = a.double() @ w.double().T + bias.double() + ps.double() * pre.double()
+    v = F.leaky_relu(v, 0.01) + post.double()
+    ref = F.leaky_relu(v * s2.double() + t2.double(), 0.01).float()
+    D = lambda t: t.to(dev())
+    ad, wd, bd, psd, s2d, t2d, pred, postd = map(D, (a, w, bias, ps, s2, t2, pre, post))
+    outs = []
+    for cfg in (4, 4, -1):
+        with options(gemm_cfg=cfg):
+            c = torch.full((m, n), float("nan"), device=dev())
+            ok(lib.casync_op_pw_gemm(ptr(ad), k, ptr(wd), ptr(bd), ptr(c), n, m, n, k, 1, ptr(pred), n, ptr(psd), ptr(postd), n,
+                                     ptr(s2d), ptr(t2d), stream()))
+            outs.append(c.cpu())
+    assert rel_err(outs[0], ref) < 2e-6
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(outs[2], ref) < 2e-6
+
+
 def test_pw_gemm_epilogue_and_strides(lib):
     """lda/ldc slices of wider buffers + pre-residual (scaled) + post-residual + affine."""
     g = torch.Generator().manual_seed(3)
