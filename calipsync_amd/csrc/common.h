@@ -75,6 +75,7 @@ struct CasyncOptions {
   int gemm_streamk = 1;      // CASYNC_GEMM_STREAMK: stream-K remainders in single-lane runs
   int gemm_glds = 2;         // CASYNC_GEMM_GLDS: LDS-DMA ring GEMM: 0 off, 1 bf16 only, 2 both types
   int gemm_cfg = -1;         // CASYNC_GEMM_CFG: force one tile configuration
+  int gemm_single64 = 4096;  // CASYNC_GEMM_SINGLE64: single-lane fp32 launches of at most this many 64x64 tiles take 64x64 tiles only (0 = cost model)
   int gemm_small_m = 1;      // CASYNC_GEMM_SMALL_M: 64x32 tiles with the K split inside the workgroup for small-M launches of the single-lane plan
   int gemm_persist = 1;      // CASYNC_GEMM_PERSIST: persistent grid of the register-staged GEMM
   int lane_streamk = 0;      // CASYNC_LANE_STREAMK: stream-K also when two or more lanes run side by side (the other lane fills tails otherwise)

@@ -980,6 +980,9 @@ int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullp
   for (const TileCfg& t : kTiles) {
     if (n % t.bn) continue;
     if (t.id == C64x32) continue;   // chosen by the rule above only
+    // single-lane fp32 plan (B < 32): 64x64 everywhere, as in the two-lane plan -- the 128-row tiles the cost model picks
+    // for its 200-tile launches stream 1.5x the bytes through each CU's LDS-DMA path (B=16: 1.81 -> 1.76 ms)
+    if (!concurrent && dtype == DT_F32 && casync_opts().gemm_single64 && n % 64 == 0 && t.id != C64x64 && t64 <= casync_opts().gemm_single64) continue;
     if (concurrent && n % 64 == 0) {
       if (conc_mode == 1 && t.id != C64x64) continue;
       if (conc_mode == 2 && t.id == C128x128) continue;
