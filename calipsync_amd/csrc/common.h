@@ -72,7 +72,7 @@ struct CasyncOptions {
                              //   lanes join before the fusion MLP and the trunk runs as one stream-K lane)
   int lane_skew = 0;         // CASYNC_LANE_SKEW: two lanes of batch/2 + skew and batch/2 - skew frames (experiment)
   int overlap = 1;           // CASYNC_OVERLAP: audio encoder on its own stream per lane
-  int gemm_streamk = 1;      // CASYNC_GEMM_STREAMK: stream-K remainders in single-lane runs
+  int gemm_streamk = 1;      // CASYNC_GEMM_STREAMK: K may be split (stream-K remainders, the small-M tile) in single-lane runs; 0 = batch-invariant bits
   int gemm_glds = 2;         // CASYNC_GEMM_GLDS: LDS-DMA ring GEMM: 0 off, 1 bf16 only, 2 both types
   int gemm_cfg = -1;         // CASYNC_GEMM_CFG: force one tile configuration
   int gemm_single64 = 4096;  // CASYNC_GEMM_SINGLE64: single-lane fp32 launches of at most this many 64x64 tiles take 64x64 tiles only (0 = cost model)

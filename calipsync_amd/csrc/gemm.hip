@@ -972,7 +972,9 @@ int pick_cfg(int m, int n, int k, bool stream_k, int dtype, bool* use_sk = nullp
   // Measured against 64x64 + stream-K (tools/experiments/small_m_gemm.sh, us per launch): (800,576,1024) 14 / 17,
   // (800,1024,512) 14 / 16, (800,512,1024) 14 / 16, (800,512,256) 7 / 9, (100,1024,1024) 14 / 14.5; from 208 tiles with
   // 32 k-tiles on it loses: (800,1024,1024) 24 / 23, (800,2048,1024) 42 / 34.  A six-stage ring is slower than four.
-  if (small_m_ok && !concurrent && dtype == DT_F32 && glds_mode() >= 2 && casync_opts().gemm_small_m && n % 32 == 0 &&
+  // (Like stream-K it splits K, i.e. changes the summation order with the batch size: gemm_streamk=0 switches both off and
+  // gives batch-invariant bits.)
+  if (small_m_ok && !concurrent && dtype == DT_F32 && glds_mode() >= 2 && casync_opts().gemm_small_m && stream_k_mode() && n % 32 == 0 &&
       (t64 <= 128 || (t64 <= 256 && nk <= 16)))
     return C64x32;
   int best = -1;

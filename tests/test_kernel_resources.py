@@ -20,6 +20,7 @@ MIN_WAVES = {
     "pw_gemm_glds_kernel<float, 64, 64, 2, 2, 2, false>": 5,     # dominant fp32 kernel: five 32-KB rings share a CU
     "pw_gemm_glds_kernel<float, 64, 64, 2, 2, 2, true>": 4,      # implicit-GEMM 3x3 conv
     "pw_gemm_glds_kernel<float, 128, 64, 2, 2, 2, false>": 3,
+    "pw_gemm_glds_kernel<float, 64, 32, 2, 1, 4, false>": 3,     # small-M tile, K split in the workgroup (48 KB of LDS: three per CU)
     "pw_gemm_ups_kernel<float, 64, 64, 2, 2, 2>": 4,
     "pw_gemm_kernel<float, 64, 64, 2, 2>": 4,
     "pw_gemm_kernel<float, 128, 32, 4, 1>": 4,
