@@ -8,7 +8,7 @@
 // One workgroup = 32 query rows of one frame x 512/nz value channels, walked in 128-channel chunks
 // (grid = B x 4 x nz).  The 32x100 score tile lives in LDS only and is computed once per
 // workgroup; nz = 4 (one chunk each, scores recomputed: QK^T is ~10 % of the work) fills the chip
-// at small batches (<= 24 frames), nz = 1 avoids the 4x Q/K re-reads once B x 4 workgroups are plenty.
+// at small batches (<= 32 frames), nz = 1 avoids the 4x Q/K re-reads once B x 4 workgroups are plenty.
 // Each V chunk is fetched into registers ahead of time (the first at kernel entry, the next under
 // the previous chunk's PV) and parked in LDS over the dead K tile, so its HBM/L2 latency hides.  QK^T and PV run on
 // v_mfma_f32_32x32x2_f32; the row softmax keeps a row on eight lanes (16 keys each) and reduces them by DPP.
@@ -207,7 +207,7 @@ int launch_cross_attention(const void* q, int ldq, const void* k, int ldk, const
     return st;
   // frame x 32-query block x channel split: enough workgroups to fill 256 CUs x ~4, no more
   const int forced_nz = casync_opts().att_nz;
-  int nz = batch <= 24 ? 4 : (batch <= 160 ? 2 : 1);   // measured: 4 wins up to 24 frames, 2 from 32 (a lane of B=64)
+  int nz = batch <= 32 ? 4 : (batch <= 160 ? 2 : 1);   // measured (round 4 kernel): 4 up to a lane of B=64 (+0.15 % over 2 there), 1 loses 0.8 %
   if (forced_nz == 1 || forced_nz == 2 || forced_nz == 4) nz = forced_nz;
   const dim3 grid(batch, 4, nz);
   if (dtype == DT_BF16)
