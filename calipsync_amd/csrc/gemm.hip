@@ -702,6 +702,7 @@ __device__ __forceinline__ void glds_body(const T* __restrict__ A, int lda, cons
   // acc -> C tile in LDS -> bias / residuals / activation -> coalesced store; ends with the ring idle
   // One wave-row block (BM / WM rows) at a time, so the staging area is BM / WM x (BN + 4) floats and a
   // two- or three-stage ring of any tile shape can hold it.
+  [[maybe_unused]] EpiCols<T> kcols;
   auto epilogue = [&] {
 #pragma unroll
     for (int h = 0; h < WM; ++h) {
@@ -729,7 +730,8 @@ __device__ __forceinline__ void glds_body(const T* __restrict__ A, int lda, cons
         }
         __syncthreads();
       }
-      epilogue_rows<T, 256, BM / WM, BN, 4, false, EUPS>(Cs, m0 + h * (BM / WM), n0, M, C, ldc, epi, tid);
+      if constexpr (WK == 2) epilogue_rows_cols<T, 256, BM / WM, BN, 4, false, false, EUPS>(Cs, m0 + h * (BM / WM), n0, M, C, ldc, epi, tid, kcols);
+      else epilogue_rows<T, 256, BM / WM, BN, 4, false, EUPS>(Cs, m0 + h * (BM / WM), n0, M, C, ldc, epi, tid);
       __syncthreads();   // staging consumed before the next block / the next loads overwrite the ring
     }
   };
@@ -812,6 +814,9 @@ __device__ __forceinline__ void glds_body(const T* __restrict__ A, int lda, cons
   int done = 0;
   for (int tile = blockIdx.x; tile < dp_tiles; tile += gridDim.x, ++done) {
     tile_origin(tile);
+    // small-M instance: one workgroup per CU, nobody to hide the epilogue's column constants behind -- request them
+    // before the k loop (the other instances keep their registers: five 64x64 workgroups per CU need <= 102)
+    if constexpr (WK == 2) kcols.load(epi, n0 + (tid % (BN / V16<T>::N)) * V16<T>::N);
     run_k(0, nk);
     if (done < 2) stamp(1 + 2 * done);
     epilogue();

@@ -107,15 +107,7 @@ __global__ __launch_bounds__(256) void dw3x3_lds_kernel(const T* __restrict__ in
   const T* inb = in + (size_t)b * H * W * C + c0;
   const int n_in = (th + 2) * WP * CSV;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  for (int i = tid; i < n_in; i += 256) {
-    const int cv = i % CSV, t = i / CSV;
-    const int r = t / WP, xc = t - r * WP;
-    const int iy = y0 - 1 + r, ix = xc - 1;
-    f32x4 v = zero;
-    if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-      v = *reinterpret_cast<const f32x4*>(inb + ((size_t)iy * W + ix) * C + cv * V);
-    dw_tile[i] = v;
-  }
+  // the taps are requested BEFORE the slab (they arrive under its loads: at small batch the launch is one latency chain)
   // 256 % CSV == 0: a thread's channel group never changes
   const int cv = tid % CSV, c = c0 + cv * V;
   float wt[9][V], bv[V];
@@ -128,6 +120,15 @@ __global__ __launch_bounds__(256) void dw3x3_lds_kernel(const T* __restrict__ in
       const f32x4 y = *reinterpret_cast<const f32x4*>(w + k * C + c + e);
       wt[k][e] = y[0]; wt[k][e + 1] = y[1]; wt[k][e + 2] = y[2]; wt[k][e + 3] = y[3];
     }
+  }
+  for (int i = tid; i < n_in; i += 256) {
+    const int cv = i % CSV, t = i / CSV;
+    const int r = t / WP, xc = t - r * WP;
+    const int iy = y0 - 1 + r, ix = xc - 1;
+    f32x4 v = zero;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+      v = *reinterpret_cast<const f32x4*>(inb + ((size_t)iy * W + ix) * C + cv * V);
+    dw_tile[i] = v;
   }
   __syncthreads();
   T* outb = out + ((size_t)b * H + y0) * W * C + c;
