@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(
     }
   };
   vfetch(cz0);
+  const float gam = gamma[0];   // (requested here, not behind two barriers)
 
   // ---- stage Q block and all K rows (rows >= 100 are zero) ----
   {
@@ -117,7 +118,6 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(
   }
   __syncthreads();   // scores complete, K dead
 
-  const float gam = gamma[0];
   for (int ci = 0; ci < cpw; ++ci) {
     const int cz = cz0 + ci;
     // ---- park this chunk's V in LDS (over K / the previous chunk) ----
