@@ -702,6 +702,7 @@ __device__ __forceinline__ void glds_body(const T* __restrict__ A, int lda, cons
   // acc -> C tile in LDS -> bias / residuals / activation -> coalesced store; ends with the ring idle
   // One wave-row block (BM / WM rows) at a time, so the staging area is BM / WM x (BN + 4) floats and a
   // two- or three-stage ring of any tile shape can hold it.
+  constexpr bool PREF64 = WK == 1 && sizeof(T) == 4 && BM == 64 && BN == 64 && NST == 2 && !CONV && !EUPS;
   [[maybe_unused]] EpiCols<T> kcols;
   auto epilogue = [&] {
 #pragma unroll
@@ -731,6 +732,7 @@ __device__ __forceinline__ void glds_body(const T* __restrict__ A, int lda, cons
         __syncthreads();
       }
       if constexpr (WK == 2) epilogue_rows_cols<T, 256, BM / WM, BN, 4, false, false, EUPS>(Cs, m0 + h * (BM / WM), n0, M, C, ldc, epi, tid, kcols);
+      else if (PREF64 && !epi.concurrent) epilogue_rows_cols<T, 256, BM / WM, BN, 4, false, false, EUPS>(Cs, m0 + h * (BM / WM), n0, M, C, ldc, epi, tid, kcols);
       else epilogue_rows<T, 256, BM / WM, BN, 4, false, EUPS>(Cs, m0 + h * (BM / WM), n0, M, C, ldc, epi, tid);
       __syncthreads();   // staging consumed before the next block / the next loads overwrite the ring
     }
@@ -817,6 +819,11 @@ __device__ __forceinline__ void glds_body(const T* __restrict__ A, int lda, cons
     // small-M instance: one workgroup per CU, nobody to hide the epilogue's column constants behind -- request them
     // before the k loop (the other instances keep their registers: five 64x64 workgroups per CU need <= 102)
     if constexpr (WK == 2) kcols.load(epi, n0 + (tid % (BN / V16<T>::N)) * V16<T>::N);
+    // single-lane plan, 64x64 fp32: same reason (B=31: 2.86 -> 2.81 ms).  With these 16 registers live across the k loop the
+    // compiler re-derives the eight fragment addresses of the two-stage loop once per pair of k-tiles (8 v_add_u32 per 32
+    // MFMAs: the loop is no longer free of vector instructions); the two-lane B=64 schedule, which never takes this
+    // branch, measured +0.7 % with that code (profiles/r4_ab_small_batch.txt), so it stays.
+    else if (PREF64 && !epi.concurrent) kcols.load(epi, n0 + (tid % (BN / V16<T>::N)) * V16<T>::N);
     run_k(0, nk);
     if (done < 2) stamp(1 + 2 * done);
     epilogue();

@@ -6,7 +6,7 @@ for round in 1 2 3; do
   for lib in "$@"; do
     export CASYNC_LIB=calipsync_amd/lib/libcasync_$lib.so
     line="round $round $lib |"
-    for B in 1 8 16; do line="$line $(timeout -k 10 100 python tools/experiments/small_forward.py $B 200 2>/dev/null | tail -1 | sed 's/ ms per forward over 200//')"; done
+    for B in 1 8 16 31; do line="$line $(timeout -k 10 100 python tools/experiments/small_forward.py $B 200 2>/dev/null | tail -1 | sed 's/ ms per forward over 200//')"; done
     bf=$(timeout -k 10 200 python bench.py --dtype bf16 --no-cpu-baseline --no-secondary --steps 20 --warmup 5 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'])")
