@@ -758,6 +758,7 @@ __device__ __forceinline__ void glds_body(const T* __restrict__ A, int lda, cons
     const int cnt = (int)((long long)(nk - k0) < it_end - it ? (long long)(nk - k0) : it_end - it);
     it += cnt;
     tile_origin(dp_tiles + t);
+    if (PREF64 && !epi.concurrent) kcols.load(epi, n0 + (tid % (BN / V16<T>::N)) * V16<T>::N);   // (as in the data-parallel part below)
     run_k(k0, cnt);
     if (cnt != nk) {
       float* slot = epi.sk_ws + (size_t)(2 * g + seg) * SLOT + tid;
