@@ -76,6 +76,8 @@ struct CasyncOptions {
   int gemm_glds = 2;         // CASYNC_GEMM_GLDS: LDS-DMA ring GEMM: 0 off, 1 bf16 only, 2 both types
   int gemm_cfg = -1;         // CASYNC_GEMM_CFG: force one tile configuration
   int gemm_single64 = 4096;  // CASYNC_GEMM_SINGLE64: single-lane fp32 launches of at most this many 64x64 tiles take 64x64 tiles only (0 = cost model)
+  int skip_early = 12;       // CASYNC_SKIP_EARLY: below this many frames (single lane, fp32) the skip half of up1.0 / up2.0's expand conv runs
+                             //   on the second stream beside the trunk and the decoder only adds up(W1a . lo) inside the depthwise kernel (0 = off)
   int gemm_small_m = 1;      // CASYNC_GEMM_SMALL_M: 64x32 tiles with the K split inside the workgroup for small-M launches of the single-lane plan
   int gemm_persist = 1;      // CASYNC_GEMM_PERSIST: persistent grid of the register-staged GEMM
   int lane_streamk = 0;      // CASYNC_LANE_STREAMK: stream-K also when two or more lanes run side by side (the other lane fills tails otherwise)
@@ -216,6 +218,9 @@ const char* conv3x3_gemm_kernel_name(int batch, int h, int wdt, int cin, int cou
 int launch_dw3x3(const void* in, const float* w, const float* bias, void* out, int batch, int h,
                  int wdt, int c, int stride, hipStream_t stream, int dtype = DT_F32);
 const char* dw3x3_kernel_name(int h, int wdt, int c, int stride, int dtype = DT_F32);
+int launch_dw3x3_ups(const float* pre, const float* g, int ldg, const float* w, const float* bias, float* out, int batch, int h,
+                     int wdt, int c, hipStream_t stream);
+const char* dw3x3_ups_kernel_name(int h, int wdt, int c);
 bool ir_fused_supported(int cin, int cout, int stride);
 // as rocprofv3 prints it; h, w > 0: the instance launch_ir_fused / launch_ir_fused_up picks for that shape
 const char* ir_fused_kernel_name(int cin, int cout, int stride, int dtype = DT_F32, bool ups = false, int h = 0, int w = 0);

@@ -182,6 +182,11 @@ UpMode up_mode(const CasyncOptions& o, const IR& b0, int dtype) {
   if (f32 && o.ups_commute && !ir_is_fused(o, b0)) return UpMode::CommuteUnfused;
   return UpMode::Materialise;
 }
+constexpr int kMinLaneBatch = 16;
+// skip_early (decode()): small single-lane batches run the skip half of up1.0 / up2.0's expand conv beside the trunk
+bool skip_early_batch(const CasyncOptions& o, int batch) {
+  return o.skip_early > 0 && batch < o.skip_early && batch < kMinLaneBatch * 2;
+}
 int64_t max_unfused_expand(const CasyncOptions& o) {
   int64_t mx = 0;
   auto see = [&](const IR& b, bool fused) {
@@ -208,7 +213,7 @@ struct Arena {
   enum Id {
     CAT4, CAT3, CAT2, CAT1, CATA, E1, E2, T0, U4, F, FM, U1, U2, U3, UG,
     A0, AC1, AC2, AC3, AC4, AC5, AC6, AE1, AE2,
-    H, TX, OX0, OX1, OX2, OX3, KX, KXF, P1Q, AO, Q, KV, COUNT
+    H, TX, OX0, OX1, OX2, OX3, KX, KXF, P1Q, AO, Q, KV, EP1, EP2, COUNT
   };
   Buf b[COUNT] = {
       {"cat4", 160 * 160 * 64, 0},  {"cat3", 80 * 80 * 128, 0},  {"cat2", 40 * 40 * 256, 0},
@@ -223,12 +228,16 @@ struct Arena {
       {"H", 100 * 1024, 0},         {"TX", 100 * 1024, 0},       {"OX0", 100 * 1024, 0},
       {"OX1", 100 * 1024, 0},       {"OX2", 100 * 1024, 0},      {"OX3", 100 * 1024, 0},
       {"KX", 100 * 1024, 0},        {"KXF", 100 * 1024, 0},      {"P1Q", 100 * 576, 0},
-      {"AO", 100 * 512, 0},         {"Q", 100 * 64, 0},          {"KV", 100 * kBlocks * kKV, 0}};
-  explicit Arena(const CasyncOptions& o) {
+      {"AO", 100 * 512, 0},         {"Q", 100 * 64, 0},          {"KV", 100 * kBlocks * kKV, 0},
+      // skip_early: W1b . skip + b of up1.0 (20x20 x 1024) and up2.0 (40x40 x 512), small batches only
+      {"EP1", 400 * 1024, 0},       {"EP2", 1600 * 512, 0}};
+  // (the two skip_early buffers exist only for the batches that use them: 4.9 MB per frame)
+  Arena(const CasyncOptions& o, int batch) {
     b[E1].per_frame = b[E2].per_frame = max_unfused_expand(o);
+    if (!skip_early_batch(o, batch)) b[EP1].per_frame = b[EP2].per_frame = 0;
   }
   static int64_t bytes(const CasyncOptions& o, int batch, int esz = 4) {
-    Arena a(o);
+    Arena a(o, batch);
     int64_t tot = 0;
     for (auto& x : a.b) tot += (x.per_frame * batch + 63) / 64 * 64;
     return tot * (int64_t)esz;
@@ -384,6 +393,8 @@ struct Plan {
   bool stream_k = false;
   bool concurrent = false;            // another lane runs beside this one
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork2 = nullptr, ev_skip = nullptr;   // skip_early: fork after the encoder, join in front of up1.0's depthwise
+  bool skip_early = false;            // set by run_forward for the trunk and the decoder of a forward alike
   // audio source: either the NCHW windows tensor (`audio`) or, when win_feat is set, the whole
   // HuBERT feature array + per-frame indices, gathered on the device (infer_api.py:99-145)
   const float* win_feat = nullptr;
@@ -583,6 +594,38 @@ struct Plan {
   void trunk() {
     using A = Arena;
     Ptr E1 = ar[A::E1], E2 = ar[A::E2], T0 = ar[A::T0];
+    // ---------------- skip_early: W1b . skip + b of up1.0 / up2.0 depend on the encoder alone.  At small batch the
+    // forward is one launch chain, so they leave it: they run on the second stream beside the
+    // fusion MLP and the attention blocks (forked behind the MLP instead: B=8 1.169 against 1.165 ms), and the decoder's depthwise kernel adds up(W1a . lo) while it stages its slab
+    // (dw3x3_ups_lds_kernel) -- at B=8 27 + 9 us become 12 us on the chain at up1.0 and 44 become 22 at up2.0, for ~20 us that
+    // the two GEMMs cost the kernels they run beside: 1.182 -> 1.165 ms, B=1 0.760 -> 0.751 ms.
+    if (skip_early) {
+      const bool fork = aux && !r.profile;
+      hipStream_t main_s = r.s;
+      if (fork) {
+        if (hipEventRecord(ev_fork2, main_s) != hipSuccess || hipStreamWaitEvent(aux, ev_fork2, 0) != hipSuccess) {
+          casync_set_error("forward: fork onto the second stream failed");
+          r.status = CASYNC_ERR_HIP;
+          return;
+        }
+        r.s = aux;
+      }
+      const Arena::Id ep[2] = {A::EP1, A::EP2};
+      const Arena::Id cat[2] = {A::CAT1, A::CAT2};
+      int hw = 20, c = 256;
+      for (int i = 0; i < 2; ++i) {
+        const IR& b0 = kUp[i][0];
+        const std::string p = b0.prefix;
+        gemm(p + ".pw1b", ar[cat[i]] + c, 2 * c, p + ".pw1b.w", ar[ep[i]], b0.cexp(), (long long)B * hw * hw, b0.cexp(), c, GemmEpilogue(),
+             p + ".pw1.b");
+        hw *= 2;
+        c = kUp[i][1].cout;
+      }
+      if (fork) {
+        if (r.status == CASYNC_OK && hipEventRecord(ev_skip, aux) != hipSuccess) r.status = CASYNC_ERR_HIP;
+        r.s = main_s;
+      }
+    }
     // ---------------- fusion (module/unet.py:323-326): tx = bn_tx(cat + mlp(cat))
     const long long M10 = (long long)B * 100;
     Ptr CATA = ar[A::CATA];
@@ -664,7 +707,27 @@ struct Plan {
         // x2 upsample before the activation.  Every launch books the flops it executes.
         gemm(std::string(b0.prefix) + ".pw1a", lo, c, std::string(b0.prefix) + ".pw1a.w", ar[A::UG], b0.cexp(),
              (long long)B * hw * hw, b0.cexp(), c, GemmEpilogue(), "-", 2.0 * B * hw * hw * (double)c * b0.cexp());
-        ir(b0, cat[i] + c, cc, T0, b0.cout, E1, E2, nullptr, ar[A::UG]);
+        if (skip_early && i < 2) {
+          // the skip half is already there (trunk()): depthwise over LReLU(pre + up(G)), then the project GEMM
+          const std::string p = b0.prefix;
+          const long long m = (long long)B * 4 * hw * hw;
+          if (i == 0 && aux && !r.profile && hipStreamWaitEvent(r.s, ev_skip, 0) != hipSuccess) {
+            casync_set_error("forward: join of the second stream failed");
+            r.status = CASYNC_ERR_HIP;
+            return;
+          }
+          const float* pre = (const float*)ar[i == 0 ? A::EP1 : A::EP2].p;
+          r.run((p + ".dwups").c_str(), dw3x3_ups_kernel_name(2 * hw, 2 * hw, b0.cexp()), 2.0 * 9 * m * b0.cexp(),
+                4.0 * ((double)m * b0.cexp() * 2 + (double)m / 4 * b0.cexp()), [&] {
+            return launch_dw3x3_ups(pre, (const float*)ar[A::UG].p, b0.cexp(), e.W(p + ".dw.w"), e.W(p + ".dw.b"), (float*)E2.p, B,
+                                    2 * hw, 2 * hw, b0.cexp(), r.s);
+          });
+          GemmEpilogue ep2;
+          ep2.act = 1;
+          gemm(p + ".pw2", E2, b0.cexp(), p + ".pw2.w", T0, b0.cout, m, b0.cout, b0.cexp(), ep2);
+        } else {
+          ir(b0, cat[i] + c, cc, T0, b0.cout, E1, E2, nullptr, ar[A::UG]);
+        }
       } else if (mode == UpMode::CommuteFused) {
         // the same commutation inside the fused kernel: G = W1a * lo by a GEMM at the low resolution, the fused
         // block runs its expand over the skip half only and adds up(G) chunk by chunk from LDS
@@ -899,7 +962,6 @@ static int ensure_streams(casync_handle h) {   // caller holds a DeviceGuard for
 // trunk_lanes = 1 ("hybrid"): the lanes join before the fusion MLP, the 10x10 trunk (all GEMMs with
 // M = B*100 rows) runs once over the whole batch with stream-K remainders, and the lanes fork again
 // for the decoder.
-constexpr int kMinLaneBatch = 16;
 
 struct FwdArgs {
   const float* x;
@@ -963,9 +1025,11 @@ static int run_forward(casync_handle h, const FwdArgs& A, hipStream_t caller, st
     Runner r;
     r.s = lane_stream(l);
     r.profile = serial;
-    Plan p{*h, Arena(o), r, bl};
+    Plan p{*h, Arena(o, A.batch), r, bl};
     p.lane = l;
     p.kv_in_encode = o.kv_early >= 2 || (o.kv_early == 1 && lanes == 1);
+    p.skip_early = lanes == 1 && h->dtype == DT_F32 && skip_early_batch(o, A.batch) &&
+                   up_mode(o, kUp[0][0], DT_F32) == UpMode::CommuteUnfused && up_mode(o, kUp[1][0], DT_F32) == UpMode::CommuteUnfused;
     p.stream_k = stream_k;
     p.concurrent = concurrent;
     p.ar.bind(A.ws, A.batch, esz);
@@ -974,6 +1038,8 @@ static int run_forward(casync_handle h, const FwdArgs& A, hipStream_t caller, st
       p.aux = h->aux[l];
       p.ev_fork = h->ev_fork[l];
       p.ev_join = h->ev_join[l];
+      p.ev_fork2 = h->ev_mid[l];     // (lane 0's ev_mid / ev_done are free in a single-lane forward)
+      p.ev_skip = h->ev_done[l];
       forked = true;
     }
     if (A.feat) {
@@ -1058,7 +1124,7 @@ int casync_profile_forward(casync_handle h, const float* x, const float* a, floa
 int64_t casync_tap(casync_handle h, const char* name, int batch, void* ws, void* dst, int64_t dst_floats,
                    casync_stream stream) {
   CASYNC_REQUIRE(h && name && ws && dst && batch > 0, "tap: bad args");
-  Arena ar(h->opt);
+  Arena ar(h->opt, batch);
   ar.bind(ws, batch, dtype_size(h->dtype));
   using A = Arena;
   struct T { const char* n; Ptr p; int ld, c, rows; };

@@ -154,6 +154,59 @@ __global__ __launch_bounds__(256) void dw3x3_lds_kernel(const T* __restrict__ in
 }
 
 
+// The same slab kernel behind an Up block's expand conv whose two halves were computed apart (engine.hip,
+// skip_early): the slab value is LReLU(pre + up(g)) -- `pre` = W1b . skip + b at the full resolution, `g` = W1a . lo at
+// half the resolution, bilinear x2 with align_corners=True (ups_tap / ups_lerp: the bits of every other consumer) --
+// and zero outside the frame (the depthwise conv pads the EXPANDED tensor).  fp32 only.
+template <int CSV>
+__global__ __launch_bounds__(256) void dw3x3_ups_lds_kernel(const float* __restrict__ pre, const float* __restrict__ g, int ldg,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ out, int H, int W, int C, int TH) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 dw_tile[];   // [(th+2)][W+2][CSV] 16-B chunks
+  const int tid = threadIdx.x;
+  const int c0 = blockIdx.x * CSV * 4, y0 = blockIdx.y * TH, b = blockIdx.z;
+  const int th = TH < H - y0 ? TH : H - y0;
+  const int WP = W + 2, Hl = H >> 1, Wl = W >> 1;
+  const float* preb = pre + (size_t)b * H * W * C + c0;
+  const float* gb = g + (size_t)b * Hl * Wl * ldg + c0;
+  const float sy = (float)(Hl - 1) / (float)(H - 1), sx = (float)(Wl - 1) / (float)(W - 1);
+  const int n_in = (th + 2) * WP * CSV;
+  const int cv = tid % CSV, c = c0 + cv * 4;
+  f32x4 wt[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wt[k] = *reinterpret_cast<const f32x4*>(w + k * C + c);
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
+  for (int i = tid; i < n_in; i += 256) {
+    const int cvi = i % CSV, t = i / CSV;
+    const int r = t / WP, xc = t - r * WP;
+    const int iy = y0 - 1 + r, ix = xc - 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+      const UpsTap ty = ups_tap(sy, iy, Hl), tx = ups_tap(sx, ix, Wl);
+      const float* gq = gb + cvi * 4;
+      const f32x4 up = ups_lerp(ty, tx, *reinterpret_cast<const f32x4*>(gq + ((size_t)ty.i0 * Wl + tx.i0) * ldg),
+                                *reinterpret_cast<const f32x4*>(gq + ((size_t)ty.i0 * Wl + tx.i1) * ldg),
+                                *reinterpret_cast<const f32x4*>(gq + ((size_t)ty.i1 * Wl + tx.i0) * ldg),
+                                *reinterpret_cast<const f32x4*>(gq + ((size_t)ty.i1 * Wl + tx.i1) * ldg));
+      const f32x4 e = *reinterpret_cast<const f32x4*>(preb + ((size_t)iy * W + ix) * C + cvi * 4) + up;
+      v = f32x4{lrelu(e[0]), lrelu(e[1]), lrelu(e[2]), lrelu(e[3])};
+    }
+    dw_tile[i] = v;
+  }
+  __syncthreads();
+  float* outb = out + ((size_t)b * H + y0) * W * C + c;
+  const int n_out = th * W;
+  for (int p = tid / CSV; p < n_out; p += 256 / CSV) {
+    const int oy = p / W, ox = p - oy * W;
+    f32x4 acc = bv;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) acc += dw_tile[((oy + ky) * WP + ox + kx) * CSV + cv] * wt[ky * 3 + kx];
+    *reinterpret_cast<f32x4*>(outb + (size_t)p * C) = f32x4{lrelu(acc[0]), lrelu(acc[1]), lrelu(acc[2]), lrelu(acc[3])};
+  }
+}
+
 // ---------------------------------------------------------------- bilinear x2
 // align_corners=True: src = dst * (in-1)/(out-1); weights as ATen computes them
 // (lambda1 = src - floor(src), lambda0 = 1 - lambda1).
@@ -420,6 +473,29 @@ static bool dw_lds_plan(int h, int wdt, int c, int stride, int dtype, int* csv, 
   *nt = (h + *th - 1) / *th;
   *th = (h + *nt - 1) / *nt;
   return true;
+}
+
+// depthwise 3x3 over LReLU(pre + up(g)) (dw3x3_ups_lds_kernel): fp32, stride 1, frames the slab plan takes
+const char* dw3x3_ups_kernel_name(int h, int wdt, int c) {
+  static thread_local char buf[64];
+  int csv = 8, th, nt;
+  dw_lds_plan(h, wdt, c, 1, DT_F32, &csv, &th, &nt);
+  snprintf(buf, sizeof(buf), "dw3x3_ups_lds_kernel<%d>", csv);
+  return buf;
+}
+int launch_dw3x3_ups(const float* pre, const float* g, int ldg, const float* w, const float* bias, float* out, int batch, int h,
+                     int wdt, int c, hipStream_t stream) {
+  CASYNC_REQUIRE(pre && g && w && bias && out, "dw3x3_ups: null pointer");
+  CASYNC_REQUIRE(batch > 0 && h > 2 && wdt > 2 && h % 2 == 0 && wdt % 2 == 0 && c % 4 == 0 && ldg >= c && ldg % 4 == 0,
+                 "dw3x3_ups: bad shape %dx%dx%d (ld %d)", h, wdt, c, ldg);
+  int csv, th, nt;
+  CASYNC_REQUIRE(dw_lds_plan(h, wdt, c, 1, DT_F32, &csv, &th, &nt), "dw3x3_ups: %dx%dx%d does not fit the slab kernel", h, wdt, c);
+  const size_t lds = (size_t)(th + 2) * (wdt + 2) * csv * 16;
+  const dim3 grid(c / 4 / csv, nt, batch);
+  if (csv == 16) hipLaunchKernelGGL(dw3x3_ups_lds_kernel<16>, grid, dim3(256), lds, stream, pre, g, ldg, w, bias, out, h, wdt, c, th);
+  else hipLaunchKernelGGL(dw3x3_ups_lds_kernel<8>, grid, dim3(256), lds, stream, pre, g, ldg, w, bias, out, h, wdt, c, th);
+  CASYNC_CHECK_HIP(hipGetLastError());
+  return CASYNC_OK;
 }
 
 const char* dw3x3_kernel_name(int h, int wdt, int c, int stride, int dtype) {

@@ -23,6 +23,7 @@ const OptField kFields[] = {
     {"gemm_glds", &CasyncOptions::gemm_glds},
     {"gemm_cfg", &CasyncOptions::gemm_cfg},
     {"gemm_small_m", &CasyncOptions::gemm_small_m},
+    {"skip_early", &CasyncOptions::skip_early},
     {"gemm_single64", &CasyncOptions::gemm_single64},
     {"gemm_persist", &CasyncOptions::gemm_persist},
     {"lane_streamk", &CasyncOptions::lane_streamk},

@@ -83,12 +83,14 @@ def test_golden_b_intermediates(net_b, golden_b, name):
     assert d < 2e-5, (name, d)
 
 
-@pytest.mark.parametrize("batch", [1, 3, 8, 12, 16, 24, 64])
+@pytest.mark.parametrize("batch", [1, 3, 5, 8, 12, 16, 24, 31, 64])
 def test_against_oracle(net, recipe_sd, batch):
     """configs[0]/[1] of BASELINE.json: B=1 plumbing and B=64 fp32 vs the CPU path; and the reference's own batch
     sizes -- FrameSynthesizer(batch_size=8) (image_infer_v1/tools/frame_synthesizer/infer_api.py:13-14), its B=8
     self-benchmark (image_infer_v1/models/unet.py:342-347), README's 8-16 -- which sit on the engine's plan switches
-    (40x40 strips from 8 frames per launch, whole-frame expand+depthwise tiles from 16, two lanes from 32)."""
+    (40x40 strips from 8 frames per launch, whole-frame expand+depthwise tiles from 12, two lanes from 32; the GEMM
+    tile rule of the single-lane plan switches with the row count: B=5 mixes the small-M tile with 64x64 + stream-K
+    launches, B=31 is the largest single lane)."""
     from oracle import unet_oracle
     torch.set_num_threads(16)
     sd = unet_oracle.to_torch(recipe_sd)
@@ -124,7 +126,8 @@ def test_default_plan_intermediates_against_oracle(net, recipe_sd):
 
 
 @pytest.mark.parametrize("opts", [dict(fuse_up=0), dict(fuse_up=0, ups_commute=0), dict(ups_commute=0), dict(ups_commute=1),
-                                  dict(fuse_ir=0), dict(fuse_ir=0, ups_commute=0), dict(fuse_dw=0), dict(fuse_min_hw=80)])
+                                  dict(fuse_ir=0), dict(fuse_ir=0, ups_commute=0), dict(fuse_dw=0), dict(fuse_min_hw=80),
+                                  dict(skip_early=0), dict(skip_early=32), dict(skip_early=32, overlap=0), dict(skip_early=32, fuse_ir=0)])
 @pytest.mark.parametrize("batch", [3, 20])
 def test_plan_switches_against_oracle(recipe_sd, opts, batch):
     """Every documented plan switch of the Up / inverted-residual stages gives the oracle's output (the workspace is sized
@@ -141,6 +144,24 @@ def test_plan_switches_against_oracle(recipe_sd, opts, batch):
     ref = unet_oracle.forward(unet_oracle.to_torch(recipe_sd), torch.from_numpy(x[pick]), torch.from_numpy(a[pick]))
     d = float((out[pick].cpu() - ref).abs().max())
     assert d < EXPECT, (opts, d)
+
+
+def test_skip_early_changes_scheduling_only(net):
+    """skip_early (B < 12: the skip half of up1.0 / up2.0's expand conv on the second stream beside the trunk, up(W1a.lo)
+    added inside the depthwise kernel) against the in-line plan: the same sums in the same order up to the GEMM's tile
+    choice, so equal to fp32 reassociation; repeatable bit for bit; taps u1 / u2 agree."""
+    for batch in (1, 5, 8, 11):
+        x, a = recipe.make_inputs_range(7, batch)
+        xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
+        on = net(xt, at).clone()
+        u_on = [net.tap(n, batch).clone() for n in ("u1", "u2")]
+        assert torch.equal(net(xt, at), on)
+        with options(net, skip_early=0):
+            off = net(xt, at)
+            u_off = [net.tap(n, batch) for n in ("u1", "u2")]
+        assert (on - off).abs().max() < 1e-5, batch
+        for p, q in zip(u_on, u_off):
+            assert (p - q).abs().max() / max(1.0, float(q.abs().max())) < 1e-5, batch
 
 
 def test_frames_independent_and_batch_invariant(net):

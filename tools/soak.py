@@ -28,7 +28,7 @@ rng = np.random.default_rng(0)
 t_end = time.time() + budget
 while time.time() < t_end:
     prec = "fp32" if rng.random() < 0.7 else "bf16"
-    b = int(rng.choice([1, 2, 8, 31, 32, 33, 63, 64, 65, 96]))
+    b = int(rng.choice([1, 2, 5, 8, 11, 12, 31, 32, 33, 63, 64, 65, 96]))
     form = int(rng.integers(0, 2))
     net = nets[prec]
     if form == 0:
