@@ -108,6 +108,40 @@ __device__ __forceinline__ f32x4 ups_at(const float* g, int ld, int y, int x) {
                   *reinterpret_cast<const f32x4*>(g + (size_t)(ty.i1 * HL + tx.i1) * ld));
 }
 
+// The same addend from a tile of g parked in LDS (round 4).  ups_at() costs a lane 52 gathered 16-B loads in its first
+// epilogue, every low-resolution value fetched 4-8 times from L2 by the lanes around it; from LDS the 32-frame launches
+// take 118 instead of 130 us (up2.0, 40x40 strips) and 82 instead of 87 us (up1.0), i.e. what the same GEMM + depthwise
+// cost without an addend (twice down2.1's 54 us / down3.1's 40 us at twice their channels): B=64 +0.95 %.  The tile holds GR rows
+// of HL pixels x 32 channels from row gy0 on, linear in pixels (LDS-DMA: a wave writes 8 pixels x 128 B per instruction),
+// the 16-B channel quads of pixel p XOR-keyed by p & 7 on the SOURCE side, so that the 16 lanes of a read -- the same
+// quad of ~8 consecutive pixels -- land on different banks.
+constexpr int kUpsTileBytes = 16384;   // 6 rows x 20 pixels (40x40 strips) or 10 x 10 (20x20 frames) x 128 B, rounded up to 4 issues
+template <int HL>
+__device__ __forceinline__ void ups_tile_load(float* sG, const float* g, int ld, int gy0, int n_rows, int wave, int lane) {
+  // g: this frame's channel slice (32 channels from the workgroup's n0); rows past the frame re-read its last row
+#pragma unroll
+  for (int j = 0; j < kUpsTileBytes / 4096; ++j) {
+    const int piece = (j * 4 + wave) * 64 + lane, p = piece >> 3, ql = piece & 7;
+    int gr = p / HL;
+    const int gx = p - gr * HL;
+    gr = gr < n_rows ? gr : n_rows - 1;
+    const int gy = gy0 + gr < HL ? gy0 + gr : HL - 1;
+    const float* src = g + (size_t)(gy * HL + gx) * ld + 4 * (ql ^ (p & 7));
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                     (void __attribute__((address_space(3)))*)(reinterpret_cast<char*>(sG) + (j * 4 + wave) * 1024), 16, 0, 0);
+  }
+}
+template <int HW>
+__device__ __forceinline__ f32x4 ups_at_lds(const float* sG, int gy0, int y, int x, int cq) {
+  constexpr int HL = HW / 2;
+  const UpsTap ty = ups_tap((float)(HL - 1) / (float)(HW - 1), y, HL), tx = ups_tap((float)(HL - 1) / (float)(HW - 1), x, HL);
+  auto at = [&](int gy, int gx) {
+    const int p = (gy - gy0) * HL + gx;
+    return *reinterpret_cast<const f32x4*>(sG + p * 32 + 4 * (cq ^ (p & 7)));
+  };
+  return ups_lerp(ty, tx, at(ty.i0, tx.i0), at(ty.i0, tx.i1), at(ty.i1, tx.i0), at(ty.i1, tx.i1));
+}
+
 // The GEMM part both kernels share: acc[i] (i-th pixel tile of this wave) = W1 tile x A rows over the whole K, k-tiles
 // arriving by LDS-DMA into a two-stage ring.  voff[j]: this lane's source offset of the wave's j-th LDS-DMA instruction
 // (rows [0, M_PAD) of a stage are A rows, then BN rows of W1); ends with the ring consumed (barrier).
@@ -239,6 +273,10 @@ __global__ __launch_bounds__(256, (FTGeom<HW, F, BN, KF, S>::occ)) void pw_dw_ke
     }
   }
   const int wn = wave % G::NT, wm = wave / G::NT;
+  // the low-resolution tile of the upsampled addend travels under the GEMM (its first vmcnt(0) + barrier cover it); it
+  // lives behind the ring / E image: the launch adds kUpsTileBytes of LDS when `ups` is set (F = 1 frame, BN = 32 only)
+  float* sG = reinterpret_cast<float*>(ring + G::lds);
+  if (ups) ups_tile_load<HW / 2>(sG, ups + (size_t)f0 * (HW / 2) * (HW / 2) * ld_ups + n0, ld_ups, 0, HW / 2, wave, lane);
   f32x4 acc[G::MTW];
   pw_dw_gemm<G, BN, KF>(ring, A, W1, a_bytes, w_bytes, voff, nk, wave, l15, q, acc);
 
@@ -257,7 +295,7 @@ __global__ __launch_bounds__(256, (FTGeom<HW, F, BN, KF, S>::occ)) void pw_dw_ke
         if (ups) {
           // + the bilinear x2 upsample of the low-resolution half of an Up block's expand conv (it commutes with the
           // 1x1 conv: common.h GemmEpilogue::ups_src), HW/2 x HW/2 frames of ld_ups channels
-          v += ups_at<HW>(ups + (size_t)(f0 + f) * (HW / 2) * (HW / 2) * ld_ups + n0 + 16 * wn + 4 * q, ld_ups, y, x);
+          v += ups_at_lds<HW>(sG, 0, y, x, 4 * wn + q);
         }
         *reinterpret_cast<f32x4*>(sE + E::at(f * HW + y, x, 4 * wn + q)) = lrelu4(v);
       }
@@ -350,6 +388,11 @@ __global__ __launch_bounds__(256, (FSGeom<HW, SR, STRIDE, BN, KF>::occ)) void pw
     }
   }
   const int wn = wave % G::NT, wm = wave / G::NT;
+  // the low-resolution rows under this strip (at most 6 of them: tap rows of the strip's first and last row inside the
+  // frame), parked behind the ring / E image while the GEMM runs (see ups_tile_load)
+  float* sG = reinterpret_cast<float*>(ring + G::lds);
+  const int gy0 = ups_tap((float)(HW / 2 - 1) / (float)(HW - 1), y0 < 0 ? 0 : y0, HW / 2).i0;
+  if (ups) ups_tile_load<HW / 2>(sG, ups + (size_t)fr * (HW / 2) * (HW / 2) * ld_ups + n0, ld_ups, gy0, kUpsTileBytes / (HW / 2 * 128), wave, lane);
   f32x4 acc[G::MTW];
   pw_dw_gemm<G, BN, KF>(ring, A, W1, a_bytes, w_bytes, voff, nk, wave, l15, q, acc);
 
@@ -368,7 +411,7 @@ __global__ __launch_bounds__(256, (FSGeom<HW, SR, STRIDE, BN, KF>::occ)) void pw
         const bool inside = y >= 0 && y < HW;
         f32x4 v = acc[i] + bias;
         if (ups && inside) {
-          v += ups_at<HW>(ups + (size_t)fr * (HW / 2) * (HW / 2) * ld_ups + n0 + 16 * wn + 4 * q, ld_ups, y, x);
+          v += ups_at_lds<HW>(sG, gy0, y, x, 4 * wn + q);
         }
         *reinterpret_cast<f32x4*>(sE + E::at(yl, x, 4 * wn + q)) = inside ? lrelu4(v) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -405,12 +448,13 @@ int launch_fs(const float* a, int lda, const float* w1, const float* b1, const f
   using G = FSGeom<HW, SR, STRIDE, BN, KF>;
   auto kern = pw_dw_strip_kernel<HW, SR, STRIDE, BN, KF>;
   static unsigned long long attr_once = 0;
-  if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)G::lds)) return st;
+  static_assert(BN == 32 && G::lds % 16 == 0 && G::lds + kUpsTileBytes <= 160 * 1024 && (HW / 2) * 128 * 6 <= kUpsTileBytes, "upsample tile");
+  if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)G::lds + kUpsTileBytes)) return st;
   const int n_nt = n / BN;
   const long long nwg = (long long)frames * G::NS * n_nt;
   const unsigned long long ab = ((unsigned long long)((long long)frames * G::P - 1) * lda + k) * 4, wb = (unsigned long long)n * k * 4;
   CASYNC_REQUIRE(nwg < (1ll << 31) && ab < (1ull << 31) && wb < (1ull << 31), "pw_dw: operand larger than 2 GiB");
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), G::lds, stream, a, lda, w1, b1, wd, bd, d, ldd, frames, k, n, n_nt,
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), G::lds + (ups ? kUpsTileBytes : 0), stream, a, lda, w1, b1, wd, bd, d, ldd, frames, k, n, n_nt,
                      (int)nwg, (unsigned)ab, (unsigned)wb, ups, ld_ups);
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
@@ -422,12 +466,14 @@ int launch_ft(const float* a, int lda, const float* w1, const float* b1, const f
   using G = FTGeom<HW, F, BN, KF, S>;
   auto kern = pw_dw_kernel<HW, F, BN, KF, S>;
   static unsigned long long attr_once = 0;
-  if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)G::lds)) return st;
+  constexpr bool UPS_OK = F == 1 && BN == 32 && (HW / 2) * (HW / 2) * 128 <= kUpsTileBytes && G::lds % 16 == 0;   // (20x20: 12.8 KB)
+  CASYNC_REQUIRE(!ups || UPS_OK, "pw_dw: no upsampled addend for %dx%d tiles of %d frames", HW, HW, F);
+  if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)G::lds + (UPS_OK ? kUpsTileBytes : 0))) return st;
   const int n_ft = (frames + F - 1) / F, n_nt = n / BN;
   const long long nwg = (long long)n_ft * n_nt;
   const unsigned long long ab = ((unsigned long long)((long long)frames * G::P - 1) * lda + k) * 4, wb = (unsigned long long)n * k * 4;
   CASYNC_REQUIRE(nwg < (1ll << 31) && ab < (1ull << 31) && wb < (1ull << 31), "pw_dw: operand larger than 2 GiB");
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), G::lds, stream, a, lda, w1, b1, wd, bd, d, ldd, frames, k, n, n_nt,
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), G::lds + (ups ? kUpsTileBytes : 0), stream, a, lda, w1, b1, wd, bd, d, ldd, frames, k, n, n_nt,
                      (int)nwg, (unsigned)ab, (unsigned)wb, ups, ld_ups);
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
