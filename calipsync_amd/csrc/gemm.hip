@@ -732,7 +732,7 @@ __device__ __forceinline__ void glds_body(const T* __restrict__ A, int lda, cons
         __syncthreads();
       }
       if constexpr (WK == 2) epilogue_rows_cols<T, 256, BM / WM, BN, 4, false, false, EUPS>(Cs, m0 + h * (BM / WM), n0, M, C, ldc, epi, tid, kcols);
-      else if (PREF64 && !epi.concurrent) epilogue_rows_cols<T, 256, BM / WM, BN, 4, false, false, EUPS>(Cs, m0 + h * (BM / WM), n0, M, C, ldc, epi, tid, kcols);
+      else if (PREF64) epilogue_rows_cols<T, 256, BM / WM, BN, 4, false, false, EUPS>(Cs, m0 + h * (BM / WM), n0, M, C, ldc, epi, tid, kcols);
       else epilogue_rows<T, 256, BM / WM, BN, 4, false, EUPS>(Cs, m0 + h * (BM / WM), n0, M, C, ldc, epi, tid);
       __syncthreads();   // staging consumed before the next block / the next loads overwrite the ring
     }
@@ -758,7 +758,7 @@ __device__ __forceinline__ void glds_body(const T* __restrict__ A, int lda, cons
     const int cnt = (int)((long long)(nk - k0) < it_end - it ? (long long)(nk - k0) : it_end - it);
     it += cnt;
     tile_origin(dp_tiles + t);
-    if (PREF64 && !epi.concurrent) kcols.load(epi, n0 + (tid % (BN / V16<T>::N)) * V16<T>::N);   // (as in the data-parallel part below)
+    if (PREF64) kcols.load(epi, n0 + (tid % (BN / V16<T>::N)) * V16<T>::N);   // (as in the data-parallel part below)
     run_k(k0, cnt);
     if (cnt != nk) {
       float* slot = epi.sk_ws + (size_t)(2 * g + seg) * SLOT + tid;
@@ -824,7 +824,7 @@ __device__ __forceinline__ void glds_body(const T* __restrict__ A, int lda, cons
     // compiler re-derives the eight fragment addresses of the two-stage loop once per pair of k-tiles (8 v_add_u32 per 32
     // MFMAs: the loop is no longer free of vector instructions); the two-lane B=64 schedule, which never takes this
     // branch, measured +0.7 % with that code (profiles/r4_ab_small_batch.txt), so it stays.
-    else if (PREF64 && !epi.concurrent) kcols.load(epi, n0 + (tid % (BN / V16<T>::N)) * V16<T>::N);
+    else if (PREF64) kcols.load(epi, n0 + (tid % (BN / V16<T>::N)) * V16<T>::N);
     run_k(0, nk);
     if (done < 2) stamp(1 + 2 * done);
     epilogue();
