@@ -517,6 +517,11 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
   p23(P0{});        // chunk NCH - 2
   p1(P1c{});        // chunk NCH - 1
   barrier(NCH - 1);
+  // the project biases of the epilogue are requested here: they arrive under the last chunk's depthwise + project phases
+  // instead of in front of the output stores
+  f32x4 bias2[G::NT3];
+#pragma unroll
+  for (int n = 0; n < G::NT3; ++n) bias2[n] = *reinterpret_cast<const f32x4*>(b2 + 16 * n + 4 * q);
   p23(P1c{});       // chunk NCH - 1
 
   // ---- epilogue: + b2, LReLU (+ residual) straight from the accumulators.  A lane holds four consecutive output
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
   T* outb = out + (size_t)b * Ho * Wo * ld_out;
 #pragma unroll
   for (int n = 0; n < G::NT3; ++n) {
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(b2 + 16 * n + 4 * q);
+    const f32x4 bias = bias2[n];
     const int c = 16 * n + 4 * q;
 #pragma unroll
     for (int i = 0; i < G::MT3; ++i) {
