@@ -240,6 +240,29 @@ def time_forward(net, x, a, warmup, steps, dev):
     return dt / steps
 
 
+def strong_leg(net, x, a, total_frames, rank, world, steps, sync, max_over_ranks, dtype="f32"):
+    """BASELINE configs[3]: a FIXED `total_frames`-frame job (4096) split over the ranks, each rank walking its contiguous
+    shard in chunks of <= 512 frames (the per-GPU size configs[3] names) through ONE Model / one arena
+    (calipsync_amd.sharding.forward_chunked).  Same timing contract as the headline: barrier + sync on both sides, max
+    over ranks.  The chunk's frames are the resident frames tiled up to the chunk size (timing is data-blind)."""
+    from calipsync_amd.sharding import forward_chunked, shard_range
+    per_rank = shard_range(total_frames, rank, world)[1]
+    chunk = min(512, max(1, per_rank))
+    reps = (per_rank + x.shape[0] - 1) // x.shape[0]
+    xs, as_ = (x, a) if reps == 1 else (x.repeat(reps, 1, 1, 1), a.repeat(reps, 1, 1, 1))
+    xs, as_ = xs[:per_rank].contiguous(), as_[:per_rank].contiguous()
+    forward_chunked(net, xs, as_, chunk, keep=False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        forward_chunked(net, xs, as_, chunk, keep=False)
+    sync()
+    sdt = max_over_ranks(time.perf_counter() - t0)
+    return {"global_batch": total_frames, "frames_per_gpu": per_rank, "chunk": chunk, "chunks_per_step": -(-per_rank // chunk),
+            "steps": steps, "value": round(total_frames * steps / sdt, 1), "unit": "frames/s",
+            "ms_per_step": round(1e3 * sdt / steps, 3), "scaling": "strong", "n_gpus": world, "dtype": dtype}
+
+
 def secondary_block(net, packed, x, a, dev, src_hash):
     """Figures next to the headline that the driver's plain `bench.py` run would otherwise never produce
     (N = 1 only; ~20 s): the reference's own benchmark shape (B=8 fp32), BASELINE configs[2] (bf16, B=512, with its
@@ -257,12 +280,26 @@ def secondary_block(net, packed, x, a, dev, src_hash):
                       "shape": "reference self-benchmark, image_infer_v1/models/unet.py:342-347"}
     # device frame loop, median of three runs per mode
     sec["e2e"] = frame_bench.run(net, dev, batch=x.shape[0])
-    # BASELINE configs[2]: bf16 engine, B=512, 512 distinct synthetic frames of the same recipe
+    # 512 distinct synthetic frames of the same recipe: the per-GPU shard of BASELINE configs[2] / configs[3]
     from calipsync_amd import recipe
-    net16 = Model(6, "hubert", precision="bf16").to(dev)
-    net16.adopt_packed(packed)
+    from calipsync_amd.sharding import forward_chunked
     x_np, a_np = recipe.make_inputs_range(0, 512)
     x16, a16 = torch.from_numpy(x_np).to(dev), torch.from_numpy(a_np).to(dev)
+    # BASELINE configs[3], single-GPU anchor: one 512-frame fp32 forward (the shard every rank of the
+    # 8-GPU job runs) with its own whole-net fractions, and the WHOLE 4096-frame job walked through this one GPU in
+    # 8 chunks of 512 through one arena -- the N = 1 point `config.strong_scaling` of an N > 1 line is divided by
+    s512 = time_forward(net, x16, a16, 2, 8, dev)
+    ex512 = sum(r["flops"] for r in net.profile(x16, a16)) / 512
+    stage32 = arch.stagewise_bound(MFMA_F32_PEAK_TF * 1e12, HBM_PEAK_GBS * 1e9, 4)
+    sec["fp32_b512"] = {"value": round(512 / s512, 1), "unit": "frames/s", "ms_per_step": round(1e3 * s512, 3), "batch": 512,
+                        "dtype": "f32", "steps": 8, "lanes": net.get_option("lanes"),
+                        "whole_net": {"mfma_frac": round(512 / s512 * work["flops"] / (MFMA_F32_PEAK_TF * 1e12), 4),
+                                      "executed_gflop_per_frame": round(ex512 / 1e9, 3),
+                                      "mfma_frac_executed": round(512 / s512 * ex512 / (MFMA_F32_PEAK_TF * 1e12), 4),
+                                      "frac_of_stagewise_bound": round(512 / s512 / stage32["frames_per_s"], 4)}}
+    sec["strong_n1"] = strong_leg(net, x16, a16, 4096, 0, 1, 4, lambda: torch.cuda.synchronize(dev), lambda t: t)
+    net16 = Model(6, "hubert", precision="bf16").to(dev)
+    net16.adopt_packed(packed)
     s16 = time_forward(net16, x16, a16, 2, 5, dev)
     per = {}
     for row in net16.profile(x16, a16):
@@ -414,28 +451,7 @@ def main():
     #      both sides, max over ranks.  Inputs are the weak leg's frames tiled (timing is data-blind).
     strong = None
     if world > 1 and args.strong_frames and not args.global_batch and not args.replay_only:
-        per_rank = shard_range(args.strong_frames, rank, world)[1]
-        chunk = min(512, max(1, per_rank))
-        reps = (chunk + x.shape[0] - 1) // x.shape[0]
-        xc, ac = x.repeat(reps, 1, 1, 1)[:chunk].contiguous(), a.repeat(reps, 1, 1, 1)[:chunk].contiguous()
-        n_full, tail = divmod(per_rank, chunk)
-
-        def strong_step():
-            for _ in range(n_full):
-                net(xc, ac)
-            if tail:
-                net(xc[:tail], ac[:tail])
-        strong_step()
-        sync()
-        s_steps = max(2, args.steps // 4)
-        t0 = time.perf_counter()
-        for _ in range(s_steps):
-            strong_step()
-        sync()
-        sdt = max_over_ranks(time.perf_counter() - t0)
-        strong = {"global_batch": args.strong_frames, "frames_per_gpu": per_rank, "chunk": chunk, "steps": s_steps,
-                  "value": round(args.strong_frames * s_steps / sdt, 1), "unit": "frames/s",
-                  "ms_per_step": round(1e3 * sdt / s_steps, 3), "scaling": "strong"}
+        strong = strong_leg(net, x, a, args.strong_frames, rank, world, max(2, args.steps // 4), sync, max_over_ranks, args.dtype)
 
     # ---- per-kernel timing with HIP events on the launch stream (rank 0)
     result = None

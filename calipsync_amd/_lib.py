@@ -54,6 +54,8 @@ _PROTOS = {
                                     C.c_int, c_f32p, c_f32p, C.c_void_p]),
     "casync_op_dw3x3": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_void_p]),
+    "casync_op_dw3x3_ups": (C.c_int, [c_f32p, c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p]),
     "casync_op_pw_dw": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_int, c_f32p, C.c_int, C.c_void_p]),
     "casync_op_pw_gemm_ups": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -86,7 +88,7 @@ _PROTOS = {
 }
 
 EXPORTS = tuple(_PROTOS)
-ABI_VERSION = 4          # == CASYNC_ABI_VERSION of include/casync_hip.h this file was written against
+ABI_VERSION = 5          # == CASYNC_ABI_VERSION of include/casync_hip.h this file was written against
 
 
 def lib_path() -> str:

@@ -1211,6 +1211,11 @@ int casync_op_dw3x3(const void* in, const float* w, const float* bias, void* out
                     int wdt, int c, int stride, casync_stream stream) {
   return launch_dw3x3(in, w, bias, out, batch, h, wdt, c, stride, (hipStream_t)stream, g_op_dtype);
 }
+int casync_op_dw3x3_ups(const float* pre, const float* g, int ldg, const float* w, const float* bias, float* out, int batch, int h,
+                        int wdt, int c, casync_stream stream) {
+  CASYNC_REQUIRE(g_op_dtype == DT_F32, "dw3x3_ups: fp32 only");
+  return launch_dw3x3_ups(pre, g, ldg, w, bias, out, batch, h, wdt, c, (hipStream_t)stream);
+}
 int casync_op_pw_dw(const void* a, int lda, const void* w1, const float* b1, const float* wd, const float* bd, void* d, int ldd,
                     int frames, int hw, int stride, int cin, int cexp, const void* ups, int ld_ups, casync_stream stream) {
   CASYNC_REQUIRE(g_op_dtype == DT_F32, "pw_dw: fp32 only");

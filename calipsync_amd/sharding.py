@@ -33,6 +33,29 @@ def shard_frames(x: torch.Tensor, audio: torch.Tensor, rank: int, world: int):
     return x[s:s + n], audio[s:s + n]
 
 
+def forward_chunked(net, x: torch.Tensor, audio: torch.Tensor, chunk: int = 512, keep: bool = True):
+    """Walk a rank's shard through ONE model in chunks of at most `chunk` frames (BASELINE configs[3]: 4096 frames over
+    8 GPUs = one 512-frame chunk per rank; fewer GPUs walk more chunks).  Every chunk reuses the model's arena (sized by
+    the first, largest chunk), launches are enqueued back to back on the current stream with no host sync in between.
+    Returns the outputs concatenated in frame order (``keep=False``: nothing -- a throughput walk that leaves no
+    4096-frame tensor behind).  Frames are independent, so this equals one forward over the whole shard
+    to fp32 rounding."""
+    if chunk <= 0:
+        raise ValueError("chunk must be positive")
+    if x.shape[0] != audio.shape[0]:
+        raise ValueError("x and audio must have the same number of frames")
+    outs = []
+    for s in range(0, x.shape[0], chunk):
+        o = net(x[s:s + chunk], audio[s:s + chunk])
+        if keep:
+            outs.append(o)
+    if not keep:
+        return None
+    if not outs:
+        return net(x, audio)          # empty shard: the model's own empty result
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+
 def packed_total() -> int:
     from . import _lib
     return int(_lib.load().casync_packed_total())

@@ -43,7 +43,7 @@ enum {
 /* ---- introspection (callable without a GPU) --------------------------- */
 /* Bumped on every change of a prototype, struct layout or the packed-weight layout; the ctypes
  * host (calipsync_amd/_lib.py) refuses a library whose version differs from the one it binds.   */
-#define CASYNC_ABI_VERSION 4
+#define CASYNC_ABI_VERSION 5
 int         casync_abi_version(void);
 const char* casync_last_error(void);           /* thread-local message         */
 
@@ -163,6 +163,14 @@ int casync_op_conv3x3(const void* in, const void* w, const float* bias, void* ou
  * w is tap-major [9][C].                                                    */
 int casync_op_dw3x3(const void* in, const float* w, const float* bias, void* out,
                     int batch, int h, int wdt, int c, int stride, casync_stream stream);
+/* The same depthwise 3x3 (pad 1, stride 1) + bias + LeakyReLU behind an Up block's first expand conv whose two
+ * input-channel halves were computed apart (engine plan `skip_early`, fp32): the conv's input is
+ * LeakyReLU(pre + up(g)), pre = W1b . skip + b at h x wdt, g = W1a . lo at (h/2) x (wdt/2), up = bilinear x2 with
+ * align_corners=True.  Replaces nn.Upsample + torch.cat + the expand conv's LeakyReLU + Conv2d(groups=C,k=3)+BN+
+ * LeakyReLU (module/unet.py:90-97, 17-30).  pre [B,h,wdt,c] NHWC, g [B,h/2,wdt/2,ldg] (first c columns used),
+ * w tap-major [9][C], out [B,h,wdt,c].  h, wdt even, c % 4 == 0, frames the LDS-slab plan takes (10..40).     */
+int casync_op_dw3x3_ups(const float* pre, const float* g, int ldg, const float* w, const float* bias, float* out,
+                        int batch, int h, int wdt, int c, casync_stream stream);
 /* Expand 1x1 conv + BN + LeakyReLU + depthwise 3x3 (pad 1, stride 1|2) + BN + LeakyReLU in one kernel, fp32, for the
  * inverted residuals below 32x32 (module/unet.py:17-30): the GEMM's output tile is whole frames, the depthwise conv
  * runs on it in LDS.  a [frames*hw*hw, lda], w1 [cexp][cin], b1 [cexp], wd [9][cexp] tap-major, bd [cexp],

@@ -358,6 +358,35 @@ def test_full_size_batch_against_oracle(recipe_sd, precision):
     assert not torch.equal(out[0], out[256])            # distinct frames really went through both lanes
 
 
+def test_chunked_walk_of_a_shard_against_oracle(recipe_sd):
+    """BASELINE configs[3] on fewer than 8 GPUs (bench.py `strong_leg`, sharding.forward_chunked): a rank walks its shard
+    in 512-frame chunks through ONE Model, i.e. one arena that the previous chunk left full of ITS intermediates.  Two
+    chunks of 512 distinct frames each; frames {0, 255, 256, 511} of the SECOND chunk (first / last frame of both lanes)
+    against the CPU oracle on exactly those frames, the first chunk against its own lone forward, and the arena is the
+    same tensor throughout."""
+    from oracle import unet_oracle
+    from calipsync_amd.sharding import forward_chunked
+    m = Model(6, "hubert").to("cuda:0")
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in recipe_sd.items()})
+    x, a = recipe.make_inputs_range(2000, 1024)
+    xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
+    out = forward_chunked(m, xt, at, 512)
+    ws = m._workspace
+    assert out.shape == (1024, 3, 160, 160) and torch.isfinite(out).all()
+    pick = [512 + i for i in (0, 255, 256, 511)]
+    torch.set_num_threads(16)
+    ref = unet_oracle.forward(unet_oracle.to_torch(recipe_sd), torch.from_numpy(x[pick]), torch.from_numpy(a[pick]))
+    d = float((out[pick].cpu() - ref).abs().max())
+    print(f"chunked walk, second chunk frames {pick} vs oracle: max {d:.3e}")
+    assert d < TOL and d < EXPECT, d
+    assert torch.equal(m(xt[:512], at[:512]), out[:512])         # the first chunk alone: same plan, same bits
+    assert m._workspace is ws                                     # one arena served every chunk
+    assert forward_chunked(m, xt[:600], at[:600], 512, keep=False) is None     # ragged tail (512 + 88), throughput mode
+    tail = m(xt[512:600], at[512:600])
+    assert (tail - out[512:600]).abs().max() < 1e-5               # an 88-frame chunk meets other tiles: rounding only
+    assert not torch.equal(out[0], out[512])
+
+
 # ------------------------------------------------------------------ scheduling edges, caller shapes
 @pytest.mark.parametrize("batch", [31, 32, 33, 63, 65])
 def test_lane_threshold_batches(net, recipe_sd, batch):

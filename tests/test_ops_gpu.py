@@ -174,6 +174,36 @@ def test_dw3x3(lib, b, h, w, c, stride):
     assert rel_err(nchw(out), ref) < 2e-6
 
 
+@pytest.mark.parametrize("frames", [1, 3, 11])
+@pytest.mark.parametrize("hw,c,ldg", [(20, 1024, 1024), (40, 512, 512), (20, 1024, 1280), (40, 512, 516), (10, 64, 64)])
+def test_dw3x3_over_the_commuted_upsample(lib, hw, c, ldg, frames):
+    """dw3x3_ups_lds_kernel (engine plan skip_early, B < 12): the depthwise conv of up1.0 (20x20x1024) / up2.0 (40x40x512)
+    whose input is LReLU(pre + up(g)) -- module/unet.py:90-97 (bilinear x2, align_corners=True, cat) behind the expand
+    conv's LeakyReLU (:17-20), then Conv2d(groups=C, k=3) + BN + LeakyReLU (:21-30) -- against PyTorch in float64 in the
+    reference's order; ragged `ldg` (g is a column slice of a wider buffer), NaN outside the columns the kernel may read."""
+    gen = torch.Generator().manual_seed(hw * 7 + c + frames)
+    pre = torch.randn(frames, c, hw, hw, generator=gen)
+    g = torch.randn(frames, c, hw // 2, hw // 2, generator=gen)
+    wt = torch.randn(c, 1, 3, 3, generator=gen) / 3
+    bias = torch.randn(c, generator=gen)
+    e = F.leaky_relu(pre.double() + F.interpolate(g.double(), scale_factor=2, mode="bilinear", align_corners=True), 0.01)
+    ref = F.leaky_relu(F.conv2d(e, wt.double(), bias.double(), 1, 1, 1, c), 0.01).float()
+    gd = torch.full((frames, hw // 2, hw // 2, ldg), float("nan"), device=dev())
+    gd[..., :c] = nhwc(g)
+    wp = wt.reshape(c, 9).T.contiguous().to(dev())
+    out = torch.full((frames, hw, hw, c), float("nan"), device=dev())
+    ok(lib.casync_op_dw3x3_ups(ptr(nhwc(pre)), ptr(gd), ldg, ptr(wp), ptr(bias.to(dev())), ptr(out), frames, hw, hw, c, stream()))
+    assert rel_err(nchw(out), ref) < 3e-6
+
+
+def test_dw3x3_over_the_commuted_upsample_rejects_bad_shapes(lib):
+    z = torch.zeros(64, device=dev())
+    for args in ((1, 21, 20, 64), (1, 20, 20, 6), (0, 20, 20, 64), (1, 160, 160, 64)):    # odd height, C % 4, no frames, no slab
+        b, h, w, c = args
+        assert lib.casync_op_dw3x3_ups(ptr(z), ptr(z), c, ptr(z), ptr(z), ptr(z), b, h, w, c, stream()) != 0
+    assert lib.casync_op_dw3x3_ups(ptr(z), ptr(z), 32, ptr(z), ptr(z), ptr(z), 1, 20, 20, 64, stream()) != 0   # ldg < c
+
+
 @pytest.mark.parametrize("b,h,w,c,stride,padv,cout", [(2, 32, 32, 128, 2, 1, 256), (2, 16, 16, 256, 2, 3, 512),
                                                         (70, 16, 16, 256, 2, 3, 512), (3, 9, 13, 64, 1, 1, 64),
                                                         (1, 7, 5, 32, 1, 0, 128), (5, 11, 11, 32, 2, 2, 64)])

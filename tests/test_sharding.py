@@ -65,3 +65,39 @@ def test_weight_broadcast_and_frame_shards_world2():
     assert g0 == g1 and g0[0] == g0[1]          # identical buffers on both ranks
     assert nz0 and nz1
     assert f0 == [0.0, 6.0, 12.0] and f1 == [18.0, 24.0]   # 5 frames -> 3 + 2, contiguous
+
+
+def test_forward_chunked_walks_a_shard_in_order():
+    """configs[3] on fewer than 8 GPUs: a rank walks its shard in chunks of <= 512 frames through one model
+    (sharding.forward_chunked).  Host logic only: a stand-in model records what it was handed."""
+    from calipsync_amd.sharding import forward_chunked
+    calls = []
+
+    def fake(x, a):
+        assert x.shape[0] == a.shape[0]
+        calls.append(x.shape[0])
+        return x[:, :1] + a[:, :1]
+
+    x = torch.arange(11, dtype=torch.float32).reshape(11, 1).repeat(1, 3)
+    a = 100 * x
+    out = forward_chunked(fake, x, a, 4)
+    assert calls == [4, 4, 3]
+    assert torch.equal(out, x[:, :1] + a[:, :1])
+    calls.clear()
+    assert forward_chunked(fake, x, a, 4, keep=False) is None and calls == [4, 4, 3]
+    calls.clear()
+    assert torch.equal(forward_chunked(fake, x, a, 512), x[:, :1] + a[:, :1]) and calls == [11]
+    assert forward_chunked(fake, x[:0], a[:0], 4).shape[0] == 0                 # an empty shard is legal
+    with pytest.raises(ValueError):
+        forward_chunked(fake, x, a, 0)
+    with pytest.raises(ValueError):
+        forward_chunked(fake, x, a[:3], 4)
+    # shards of the 4096-frame job: every rank's walk covers its range exactly once
+    from calipsync_amd.sharding import shard_range
+    for world in (1, 2, 3, 4, 8):
+        seen = []
+        for r in range(world):
+            s, n = shard_range(4096, r, world)
+            seen += [(s + c, min(512, n - c)) for c in range(0, n, 512)]
+        assert sum(n for _, n in seen) == 4096 and [s for s, _ in seen] == sorted(s for s, _ in seen)
+        assert all(seen[i][0] + seen[i][1] == seen[i + 1][0] for i in range(len(seen) - 1))
