@@ -96,6 +96,10 @@ struct CasyncOptions {
                              //   (round 4, column-walking epilogue: B=12 1.609 -> 1.584 ms with them, B=8 1.261 -> 1.275 ms)
   int fuse_dw_min40 = 8;     // CASYNC_FUSE_DW_MIN40: frames per launch from which the 40x40 strips are used (5 strips per frame:
                              //   B=8 1.312 -> 1.296 ms, B=1 0.841 -> 0.848 ms)
+  int fuse_dw_bf16 = 2;      // CASYNC_FUSE_DW_BF16: the same fusion in the bf16 engine (pw_dw_bf16.hip: 64-channel tiles, bf16 E image):
+                             //   1 = 10x10 / 16x16 / 20x20 blocks, 2 = also the 40x40 strips, 0 = GEMM + depthwise launches
+  int fuse_dw_bf16_bn = 64;  // CASYNC_FUSE_DW_BF16_BN: channel tile of its 10x10 / 16x16 instances (64 or 128)
+  int fuse_dw_bf16_min = 12; // CASYNC_FUSE_DW_BF16_MIN: frames per launch from which it is used
   int dw_lds = 1;            // CASYNC_DW_LDS: LDS-slab depthwise kernel
   int dw_lds_bytes = 32768;  // CASYNC_DW_LDS_BYTES
   int att_nz = 0;            // CASYNC_ATT_NZ: channel split of the attention kernel (0 = by batch)
@@ -247,6 +251,11 @@ const char* pw_dw_kernel_name(int hw, int cexp, int frames, int stride = 1);
 // activation (an Up block's upsampled half, see GemmEpilogue::ups_src)
 int launch_pw_dw(const void* a, int lda, const void* w1, const float* b1, const float* wd, const float* bd, void* d, int ldd,
                  int frames, int hw, int stride, int cin, int cexp, hipStream_t stream, const void* ups = nullptr, int ld_ups = 0);
+// the bf16 engine's expand + depthwise kernel (pw_dw_bf16.hip): a, w1, d bf16; b1, wd, bd fp32; cin % 32 == 0, cexp % 64 == 0
+bool pw_dw_bf16_supported(int hw, int cin, int cexp, int stride);
+const char* pw_dw_bf16_kernel_name(int hw, int cexp, int frames, int stride = 1);
+int launch_pw_dw_bf16(const void* a, int lda, const void* w1, const float* b1, const float* wd, const float* bd, void* d, int ldd,
+                      int frames, int hw, int stride, int cin, int cexp, hipStream_t stream);
 int launch_upsample2x(const void* in, void* out, int ldc, int batch, int h, int wdt, int c,
                       hipStream_t stream, int dtype = DT_F32);
 int launch_cross_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,

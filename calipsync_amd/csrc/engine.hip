@@ -491,6 +491,15 @@ struct Plan {
         return launch_pw_dw(in, ld_in, e.W(w1name), e.W(p + ".pw1.b"), e.W(p + ".dw.w"), e.W(p + ".dw.b"), e2,
                             b.cexp(), B, b.hw_in, b.stride, k_in, b.cexp(), r.s, ups.p, b.cexp());
       });
+    } else if (dt() == DT_BF16 && !ups.p && o.fuse_dw_bf16 && (b.hw_in < 40 || o.fuse_dw_bf16 >= 2) && B >= o.fuse_dw_bf16_min &&
+               pw_dw_bf16_supported(b.hw_in, k_in, b.cexp(), b.stride)) {
+      // the bf16 engine's counterpart (round 5): 64-channel tiles, bf16 E image in LDS; E never reaches HBM
+      r.run((p + ".pw1dw").c_str(), pw_dw_bf16_kernel_name(b.hw_in, b.cexp(), B, b.stride),
+            2.0 * (m_in * (double)k_in * b.cexp() + 9.0 * m_out * b.cexp()),
+            2.0 * (m_in * (double)k_in + (double)b.cexp() * k_in + (double)m_out * b.cexp()), [&] {
+        return launch_pw_dw_bf16(in, ld_in, e.WG(w1name), e.W(p + ".pw1.b"), e.W(p + ".dw.w"), e.W(p + ".dw.b"), e2, b.cexp(), B,
+                                 b.hw_in, b.stride, k_in, b.cexp(), r.s);
+      });
     } else {
       GemmEpilogue ep1;
       ep1.act = 1;
@@ -1218,7 +1227,10 @@ int casync_op_dw3x3_ups(const float* pre, const float* g, int ldg, const float* 
 }
 int casync_op_pw_dw(const void* a, int lda, const void* w1, const float* b1, const float* wd, const float* bd, void* d, int ldd,
                     int frames, int hw, int stride, int cin, int cexp, const void* ups, int ld_ups, casync_stream stream) {
-  CASYNC_REQUIRE(g_op_dtype == DT_F32, "pw_dw: fp32 only");
+  if (g_op_dtype == DT_BF16) {
+    CASYNC_REQUIRE(!ups, "pw_dw (bf16): no upsampled addend");
+    return launch_pw_dw_bf16(a, lda, w1, b1, wd, bd, d, ldd, frames, hw, stride, cin, cexp, (hipStream_t)stream);
+  }
   return launch_pw_dw(a, lda, w1, b1, wd, bd, d, ldd, frames, hw, stride, cin, cexp, (hipStream_t)stream, ups, ld_ups);
 }
 int casync_op_pw_gemm_ups(const void* a, int lda, const void* w, const float* bias, void* c, int ldc, int m, int n, int k, int act,

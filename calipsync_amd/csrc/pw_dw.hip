@@ -31,6 +31,7 @@
 
 #include "common.h"
 #include "ir_common.h"
+#include "pw_dw_common.h"
 
 namespace {
 
@@ -46,18 +47,6 @@ struct ETile {
   // float offset of channel quad `cq` of the pixel in image row R, column x (-1 .. HW)
   static __device__ __forceinline__ int at(int R, int x, int cq) { return (R * WP + x + 1) * BN + ((cq ^ ((x + 1) & 7)) << 2); }
 };
-// Output rows are cut into RS runs per frame / strip so that NQ x WO x runs work items fill the 256 threads evenly.
-constexpr int pick_runs(int per_run_items, int rows, int blocks) {
-  int best = 1;
-  double best_u = 0;
-  for (int rs = 1; rs <= 8 && rs <= rows; ++rs) {
-    const int items = per_run_items * rs * blocks, rounds = (items + 255) / 256;
-    const double u = (double)items / (256.0 * rounds);
-    if (u > best_u + 0.02) best = rs, best_u = u;
-  }
-  return best;
-}
-
 // KF = floats per k-tile row: 32 (128-B rows, gemm.hip's ring) or 16 (64-B rows: half the ring, so that the whole
 // working set of a workgroup stays near the 32 KB of the 64x64 GEMM tiles it shares the CUs with -- a workgroup that
 // fills a CU's LDS shuts the other lane's kernels out, measured -2 % end to end with 74 KB rings)
@@ -80,21 +69,6 @@ struct FTGeom {
   static_assert(lds <= 160 * 1024, "LDS budget");
   static_assert(2 * E::ROWF * 4 < 65536, "tap row offsets are DS immediates");
 };
-
-__device__ __forceinline__ void ft_dma16(const void* base, unsigned bytes, void* lds, int voff, int soff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000),
-                                           (void __attribute__((address_space(3)))*)lds, 16, voff, soff, 0, 0);
-#endif
-}
-
-// swizzle key of stage row r: 128-B rows: (r >> 1) & 7 (gemm.hip); 64-B rows: a 4-entry table by (r >> 2) & 3 chosen so
-// that the sixteen rows of a ds_read_b128 service group fall on sixteen different 16-B bank slots
-template <int KF>
-__device__ __forceinline__ int ft_key(int r) {
-  if constexpr (KF == 32) return (r >> 1) & 7;
-  else return (0x1320 >> (4 * ((r >> 2) & 3))) & 3;      // {0, 2, 3, 1}
-}
 
 // four channels of the bilinear x2 upsample (align_corners=True) of a low-resolution tensor g [HL x HL pixels][ld] at
 // high-resolution pixel (y, x): the addend of an Up block's commuted expand conv (common.h GemmEpilogue::ups_src)

@@ -37,6 +37,9 @@ const OptField kFields[] = {
     {"fuse_dw", &CasyncOptions::fuse_dw},
     {"fuse_dw_min", &CasyncOptions::fuse_dw_min},
     {"fuse_dw_min40", &CasyncOptions::fuse_dw_min40},
+    {"fuse_dw_bf16", &CasyncOptions::fuse_dw_bf16},
+    {"fuse_dw_bf16_bn", &CasyncOptions::fuse_dw_bf16_bn},
+    {"fuse_dw_bf16_min", &CasyncOptions::fuse_dw_bf16_min},
     {"dw_lds", &CasyncOptions::dw_lds},
     {"dw_lds_bytes", &CasyncOptions::dw_lds_bytes},
     {"att_nz", &CasyncOptions::att_nz},

@@ -192,7 +192,8 @@ def test_dw3x3_over_the_commuted_upsample(lib, hw, c, ldg, frames):
     gd[..., :c] = nhwc(g)
     wp = wt.reshape(c, 9).T.contiguous().to(dev())
     out = torch.full((frames, hw, hw, c), float("nan"), device=dev())
-    ok(lib.casync_op_dw3x3_ups(ptr(nhwc(pre)), ptr(gd), ldg, ptr(wp), ptr(bias.to(dev())), ptr(out), frames, hw, hw, c, stream()))
+    pd, bd = nhwc(pre), bias.to(dev())       # named: a temporary's block may be handed to the next allocation
+    ok(lib.casync_op_dw3x3_ups(ptr(pd), ptr(gd), ldg, ptr(wp), ptr(bd), ptr(out), frames, hw, hw, c, stream()))
     assert rel_err(nchw(out), ref) < 3e-6
 
 
@@ -577,3 +578,52 @@ def test_dw3x3_bf16(bf16_ops, b, h, w, c, stride):
     ok(lib.casync_op_dw3x3(ptr(xd), ptr(wp), ptr(bd), ptr(out), b, h, w, c, stride, stream()))
     assert rel_err(nchw(out.float()), ref) < 2 ** -8
 
+
+
+@pytest.mark.parametrize("bn", [64, 128])
+@pytest.mark.parametrize("hw,stride,cin,cexp,frames", [
+    (10, 1, 512, 1024, 5), (10, 1, 1024, 2048, 2), (10, 1, 256, 512, 33), (16, 1, 256, 512, 3), (20, 1, 256, 512, 2),
+    (20, 2, 256, 512, 3), (20, 1, 128, 256, 2), (10, 1, 64, 128, 1), (20, 1, 512, 1024, 3),
+    (40, 1, 128, 256, 3), (40, 2, 128, 256, 2), (40, 1, 32, 64, 1), (40, 2, 64, 128, 17), (40, 1, 256, 512, 2)])
+def test_pw_dw_fused_bf16(bf16_ops, hw, stride, cin, cexp, frames, bn):
+    """The bf16 engine's expand 1x1 + LeakyReLU + depthwise 3x3 + LeakyReLU kernel (pw_dw_bf16.hip: 64- / 128-channel tiles,
+    bf16 E image in LDS) vs PyTorch in float64 on the SAME bf16-rounded operands, E rounded to bf16 where the kernel rounds
+    it: what is left is the last-bit rounding of E (fp32 vs fp64 sums) and of the bf16 output.  Odd frame counts, strips,
+    stride 2, strided operands, untouched columns beside D."""
+    lib = bf16_ops
+    if bn == 128 and hw > 16:
+        pytest.skip("128-channel tiles exist for the 10x10 / 16x16 instances only")
+    g = torch.Generator().manual_seed(hw * 100 + cin + frames)
+    x = torch.randn(frames, cin, hw, hw, generator=g).bfloat16()
+    w1 = (torch.randn(cexp, cin, generator=g) / cin ** 0.5).bfloat16()
+    b1 = torch.randn(cexp, generator=g) * 0.3
+    wd = torch.randn(cexp, 1, 3, 3, generator=g) / 3
+    bd = torch.randn(cexp, generator=g) * 0.3
+    e = F.leaky_relu(F.conv2d(x.double(), w1.double()[:, :, None, None], b1.double()), 0.01).float().bfloat16()
+    ref = F.leaky_relu(F.conv2d(e.double(), wd.double(), bd.double(), stride, 1, 1, cexp), 0.01).float()
+    ho = ref.shape[2]
+    lda, ldd = cin + 32, cexp + 16
+    xin = torch.full((frames, hw, hw, lda), 5.0, dtype=torch.bfloat16)
+    xin[..., 32:] = x.permute(0, 2, 3, 1)
+    xin = xin.to(dev())
+    out = torch.full((frames, ho, ho, ldd), -7.0, device=dev(), dtype=torch.bfloat16)
+    wdp = wd.reshape(cexp, 9).T.contiguous().to(dev())          # tap-major [9][C], fp32
+    w1d, b1d, bdd = w1.to(dev()), b1.to(dev()), bd.to(dev())
+    with options(fuse_dw_bf16_bn=bn):
+        ok(lib.casync_op_pw_dw(xin.data_ptr() + 32 * 2, lda, ptr(w1d), ptr(b1d), ptr(wdp), ptr(bdd), out.data_ptr() + 16 * 2, ldd,
+                               frames, hw, stride, cin, cexp, 0, 0, stream()))
+    o = out.float().cpu()
+    assert (o[..., :16] == -7).all()
+    got = o[..., 16:].permute(0, 3, 1, 2)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) / scale < 2 ** -7
+    assert float((got - ref).abs().mean()) / scale < 2 ** -11
+
+
+def test_pw_dw_fused_bf16_rejects_bad_shapes(bf16_ops):
+    lib = bf16_ops
+    z = torch.zeros(4096, device=dev(), dtype=torch.bfloat16)
+    zf = torch.zeros(4096, device=dev())
+    for hw, stride, cin, cexp in ((12, 1, 64, 128), (10, 2, 64, 128), (20, 1, 48, 128), (20, 1, 64, 96)):
+        assert lib.casync_op_pw_dw(ptr(z), cin, ptr(z), ptr(zf), ptr(zf), ptr(zf), ptr(z), cexp, 1, hw, stride, cin, cexp, 0, 0, stream()) != 0
+    assert lib.casync_op_pw_dw(ptr(z), 64, ptr(z), ptr(zf), ptr(zf), ptr(zf), ptr(z), 128, 1, 10, 1, 64, 128, ptr(zf), 128, stream()) != 0
