@@ -98,7 +98,7 @@ struct CasyncOptions {
                              //   B=8 1.312 -> 1.296 ms, B=1 0.841 -> 0.848 ms)
   int fuse_dw_bf16 = 2;      // CASYNC_FUSE_DW_BF16: the same fusion in the bf16 engine (pw_dw_bf16.hip: 64-channel tiles, bf16 E image):
                              //   1 = 10x10 / 16x16 / 20x20 blocks, 2 = also the 40x40 strips, 0 = GEMM + depthwise launches
-  int fuse_dw_bf16_bn = 64;  // CASYNC_FUSE_DW_BF16_BN: channel tile of its 10x10 / 16x16 instances (64 or 128)
+  int fuse_dw_bf16_bn = 128; // CASYNC_FUSE_DW_BF16_BN: channel tile of its 10x10 / 16x16 instances (64 or 128)
   int fuse_dw_bf16_min = 12; // CASYNC_FUSE_DW_BF16_MIN: frames per launch from which it is used
   int dw_lds = 1;            // CASYNC_DW_LDS: LDS-slab depthwise kernel
   int dw_lds_bytes = 32768;  // CASYNC_DW_LDS_BYTES

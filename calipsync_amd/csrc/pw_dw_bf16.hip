@@ -87,11 +87,18 @@ __device__ __forceinline__ void pw_dw_gemm_b(char* ring, const bf16_t* __restric
 #pragma unroll
   for (int i = 0; i < G::MTW; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Two k-tiles in flight on a two-stage ring.  With matrix instructions 8 x faster than fp32 a k-tile's MFMAs (~400 cycles)
+  // are far shorter than the latency of its LDS-DMA fill, so the fp32 kernel's schedule -- k-tile kt + 1 requested at the
+  // top of iteration kt -- leaves the loop waiting on one fill per iteration (measured: 1,600-1,750 cycles per k-tile and CU
+  // on up2.0 / up1.0 for ~700 of LDS time).  Here every fragment of k-tile kt is read into registers first; a second barrier
+  // says "everyone has read stage kt & 1", the fill of k-tile kt + 2 goes into that stage at once, and the MFMAs of k-tile
+  // kt run under it: a fill has two iterations to arrive.
   issue(0, 0);
+  if (nk > 1) issue(1, 1);
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of k-tile kt has landed
-    __syncthreads();                                   // ... everyone's; and everyone is done reading the other stage
-    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::LPT) : "memory");   // this wave's part of k-tile kt has landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // (k-tile kt + 1 may still be in flight)
+    __syncthreads();                                                                  // ... everyone's
     const char* st = ring + (kt & 1) * G::STAGE;
     bf16x8 fw[2], fa[G::MTW];
 #pragma unroll
@@ -101,6 +108,11 @@ __device__ __forceinline__ void pw_dw_gemm_b(char* ring, const bf16_t* __restric
       // a tile index past the end (odd tile count) recomputes the last tile and never stores it
       const int t = mg + G::MG * i < G::MT ? mg + G::MG * i : G::MT - 1;
       fa[i] = *reinterpret_cast<const bf16x8*>(st + 16 * t * KROWB + frag);
+    }
+    if (kt + 2 < nk) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments are in registers
+      __syncthreads();                                     // everyone's: the stage is free
+      issue(kt + 2, kt & 1);
     }
 #pragma unroll
     for (int i = 0; i < G::MTW; ++i)

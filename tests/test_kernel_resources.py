@@ -39,6 +39,10 @@ MIN_WAVES = {
     "pw_dw_kernel<20, 1, 32, 16, 1>": 5,
     "pw_dw_strip_kernel<40, 8, 1, 32, 16>": 4,                   # (57 KB of LDS: two workgroups per CU either way)
     "pw_dw_strip_kernel<40, 4, 2, 32, 16>": 4,
+    "pw_dw_bf16_kernel<10, 2, 128, 1>": 2,                       # bf16 expand + depthwise (round 5): 2 workgroups per CU by LDS and registers
+    "pw_dw_bf16_kernel<20, 1, 64, 1>": 2,
+    "pw_dw_bf16_strip_kernel<40, 8, 1, 64>": 2,
+    "pw_dw_bf16_strip_kernel<40, 4, 2, 64>": 2,
     "inc_kernel<float>": 4,
     "outc_kernel<float>": 4,
 }
