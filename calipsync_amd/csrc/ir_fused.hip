@@ -287,17 +287,32 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
   gload(0, P0{});
   stage_w1(0, P0{});
   bias_load(0);
-  // ---- A fragments of this wave's halo rows: HBM -> registers, once (zeros outside the image;
-  //      MFMA pad rows >= HP are zero too and never stored) ----
+  // ---- this lane's halo pixels, worked out ONCE (round 5): tile wave * MT1 + i is a scalar, so the walk of halo_px() is
+  //      scalar arithmetic plus one add of l15; the A-fragment loads, the E addresses, the border masks, the G taps and the
+  //      parked residual tile all read these registers (round 4 recomputed the walk in each of them: with the 64-bit
+  //      address arithmetic of the loads and stores, prologue + epilogue were half of all vector instructions of the
+  //      four-chunk blocks, profiles/r4_mfma_busy.json) ----
+  int hyv[G::MT1], hxv[G::MT1];
+  bool livev[G::MT1], okv[G::MT1];
+#pragma unroll
+  for (int i = 0; i < G::MT1; ++i) {
+    livev[i] = halo_px<G>(wave_s * G::MT1 + i, l15, hyv[i], hxv[i]);
+    const int iy = iy0 + hyv[i], ix = ix0 + hxv[i];
+    okv[i] = livev[i] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+  }
+  // ---- A fragments of this wave's halo rows: HBM -> registers, once.  Buffer-addressed: the frame is the buffer, a
+  //      lane's offset is 32-bit and a pixel outside the image (or an MFMA pad row) takes an offset past the end, which
+  //      the hardware answers with zeros -- no 64-bit address per load, no exec-masked zero fill ----
+  constexpr unsigned kOob = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(inb), 0, (unsigned)H * W * ld_in * (unsigned)sizeof(T), 0x00020000);
   f32x4 fa[G::MT1][G::KG];
 #pragma unroll
   for (int i = 0; i < G::MT1; ++i) {
-    int hy, hx;
-    const bool live = halo_px<G>(wave * G::MT1 + i, l15, hy, hx);
+    const int hy = hyv[i], hx = hxv[i];
     const int iy = iy0 + hy, ix = ix0 + hx;
-    const bool ok = live && iy >= 0 && iy < H && ix >= 0 && ix < W;
-    const T* src = inb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * ld_in + 4 * q;
+    const bool ok = okv[i];
     if constexpr (UPS == 1) {
+      const T* src = inb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * ld_in + 4 * q;
       // same arithmetic as upsample2x_kernel / ATen: src = dst*(in-1)/(out-1), l1 = frac, l0 = 1-l1
       const int Hl = H >> 1, Wl = W >> 1;
       const float sy = (float)(Hl - 1) / (float)(H - 1), sx = (float)(Wl - 1) / (float)(W - 1);
@@ -324,9 +339,10 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
         fa[i][g] = v;
       }
     } else {
+      const unsigned aoff = ok ? (unsigned)(((iy * W + ix) * ld_in + 4 * q) * (int)sizeof(T)) : kOob;
 #pragma unroll
       for (int g = 0; g < G::KG; ++g)
-        fa[i][g] = ok ? ld4(src + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        fa[i][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(aoff + 64u * g), 0, 0));
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
@@ -346,12 +362,9 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
   bool ein[G::MT1];
 #pragma unroll
   for (int i = 0; i < G::MT1; ++i) {
-    int hy, hx;
-    const bool live = halo_px<G>(wave * G::MT1 + i, l15, hy, hx);
-    const int iy = iy0 + hy, ix = ix0 + hx;
-    ein[i] = !border || (iy >= 0 && iy < H && ix >= 0 && ix < W);
+    ein[i] = !border || okv[i] || !livev[i];
 #pragma unroll
-    for (int n = 0; n < G::NT1; ++n) ewr[i][n] = live ? e_off<STRIDE, CC, G::IW>(hy, hx, 4 * n + q) : -1;
+    for (int n = 0; n < G::NT1; ++n) ewr[i][n] = livev[i] ? e_off<STRIDE, CC, G::IW>(hyv[i], hxv[i], 4 * n + q) : -1;
   }
   // UPG: where the first of the four taps of each of this lane's halo pixels sits in the G tile, and the four corner
   // weights.  The other taps are ALWAYS the next column / row of the tile (immediate offsets): where the reference
@@ -364,10 +377,8 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
     const float sy = (float)(Hl - 1) / (float)(H - 1), sx = (float)(Wl - 1) / (float)(W - 1);
 #pragma unroll
     for (int i = 0; i < G::MT1; ++i) {
-      int hy, hx;
-      const bool live = halo_px<G>(wave * G::MT1 + i, l15, hy, hx);
-      const int iy = iy0 + hy, ix = ix0 + hx;
-      const bool ok = live && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const int iy = iy0 + hyv[i], ix = ix0 + hxv[i];
+      const bool ok = okv[i];
       const UpsTap ty = ups_tap(sy, ok ? iy : (iy0 < 0 ? 0 : iy0), Hl), tx = ups_tap(sx, ok ? ix : (ix0 < 0 ? 0 : ix0), Wl);
       go[i] = ((ty.i0 - gy0) * G::GW + (tx.i0 - gx0)) * CC + 4 * q;
       gw[i] = f32x4{ty.l0 * tx.l0, ty.l0 * tx.l1, ty.l1 * tx.l0, ty.l1 * tx.l1};
@@ -535,8 +546,8 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
       __syncthreads();   // every wave is done with E / W, which the parked tile overlays
 #pragma unroll
       for (int i = 0; i < G::MT1; ++i) {
-        int hy, hx;
-        if (halo_px<G>(wave * G::MT1 + i, l15, hy, hx) && hy >= 1 && hy <= G::TH && hx >= 1 && hx <= TW) {
+        int hy, hx;   // (recomputed: keeping the prologue's coordinates alive across the chunk loop costs down1.1 its third wave)
+        if (halo_px<G>(wave_s * G::MT1 + i, l15, hy, hx) && hy >= 1 && hy <= G::TH && hx >= 1 && hx <= TW) {
           const int p = (hy - 1) * TW + hx - 1;
           float* dst = sX + p * CIN;
 #pragma unroll
@@ -546,24 +557,35 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
       __syncthreads();
     }
   }
+  // buffer-addressed stores (round 5): one 32-bit offset per output pixel, the channel tile as an instruction immediate, a
+  // pixel past the image edge as an offset past the end of the frame (the store is dropped)
   T* outb = out + (size_t)b * Ho * Wo * ld_out;
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(outb, 0, (unsigned)Ho * Wo * ld_out * (unsigned)sizeof(T), 0x00020000);
+  unsigned ooff[G::MT3];
+  [[maybe_unused]] unsigned roff[G::MT3];
+  int pv[G::MT3];
+#pragma unroll
+  for (int i = 0; i < G::MT3; ++i) {
+    const int py = wave_s * G::MT3 + i, px = l15;          // tile i of this wave = output row py of the workgroup's tile (TW = 16)
+    const int oy = oy0 + py, ox = ox0 + px;
+    const bool ok = oy < Ho && ox < Wo;
+    pv[i] = py * TW + px;
+    ooff[i] = ok ? (unsigned)(((oy * Wo + ox) * ld_out + 4 * q) * (int)sizeof(T)) : kOob;
+    roff[i] = ok ? (unsigned)(((oy * W + ox) * ld_in + 4 * q) * (int)sizeof(T)) : kOob;
+  }
 #pragma unroll
   for (int n = 0; n < G::NT3; ++n) {
     const f32x4 bias = bias2[n];
     const int c = 16 * n + 4 * q;
 #pragma unroll
     for (int i = 0; i < G::MT3; ++i) {
-      const int p = 16 * (wave * G::MT3 + i) + l15;      // acc3 rows = 4 consecutive output channels
-      const int py = p / TW, px = p - py * TW;
-      const int oy = oy0 + py, ox = ox0 + px;
-      if (oy < Ho && ox < Wo) {
-        f32x4 v = lrelu4(acc3[i][n] + bias);
-        if (res) {   // stride 1, CIN == COUT: + the block input pixel
-          if constexpr (G::RESC && sizeof(T) == 4) v += *reinterpret_cast<const f32x4*>(sX + p * CIN + (((c >> 2) ^ xkey<CIN>(p)) << 2));
-          else v += ld4(inb + ((size_t)oy * W + ox) * ld_in + c);
-        }
-        st4(outb + ((size_t)oy * Wo + ox) * ld_out + c, v);
+      const int p = pv[i];                                 // acc3 rows = 4 consecutive output channels
+      f32x4 v = lrelu4(acc3[i][n] + bias);
+      if (res) {   // stride 1, CIN == COUT: + the block input pixel
+        if constexpr (G::RESC && sizeof(T) == 4) v += *reinterpret_cast<const f32x4*>(sX + p * CIN + (((c >> 2) ^ xkey<CIN>(p)) << 2));
+        else v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(roff[i] + 64u * n), 0, 0));
       }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, (int)(ooff[i] + 64u * n), 0, 0);
     }
   }
   if (stamps) {
