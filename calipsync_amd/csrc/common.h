@@ -97,6 +97,8 @@ struct CasyncOptions {
                              //   (round 4, column-walking epilogue: B=12 1.609 -> 1.584 ms with them, B=8 1.261 -> 1.275 ms)
   int fuse_dw_min40 = 8;     // CASYNC_FUSE_DW_MIN40: frames per launch from which the 40x40 strips are used (5 strips per frame:
                              //   B=8 1.312 -> 1.296 ms, B=1 0.841 -> 0.848 ms)
+  int fuse_dw_deep = 10;     // CASYNC_FUSE_DW_DEEP: launches of 2 .. this - 1 frames take one-frame tiles with 128-B k-tile rows and a four-stage
+                             //   ring (10x10 / 16x16, stride 1): the small-batch form of the fused expand + depthwise kernel (0 = off)
   int fuse_dw_bf16 = 2;      // CASYNC_FUSE_DW_BF16: the same fusion in the bf16 engine (pw_dw_bf16.hip: 64-channel tiles, bf16 E image):
                              //   1 = 10x10 / 16x16 / 20x20 blocks, 2 = also the 40x40 strips, 0 = GEMM + depthwise launches
   int fuse_dw_bf16_bn = 128; // CASYNC_FUSE_DW_BF16_BN: channel tile of its 10x10 / 16x16 instances (64 or 128)

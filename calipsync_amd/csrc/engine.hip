@@ -481,7 +481,9 @@ struct Plan {
       return;
     }
     // (from fuse_dw_min = 12 frames per launch: below that its whole-frame tiles are too few to fill the chip -- B=1 0.92 vs 0.82 ms)
-    if (dt() == DT_F32 && o.fuse_dw && (b.hw_in < 40 || o.fuse_dw >= 2) && B >= (b.hw_in == 40 ? o.fuse_dw_min40 : o.fuse_dw_min) &&
+    // (below fuse_dw_deep frames per launch -- round 5 -- the stride-1 blocks take its one-frame tiles with a four-stage ring)
+    const bool deep = b.hw_in <= 16 && b.stride == 1 && !ups.p && B >= 2 && B < o.fuse_dw_deep;
+    if (dt() == DT_F32 && o.fuse_dw && (b.hw_in < 40 || o.fuse_dw >= 2) && (deep || B >= (b.hw_in == 40 ? o.fuse_dw_min40 : o.fuse_dw_min)) &&
         pw_dw_supported(b.hw_in, k_in, b.cexp(), b.stride)) {
       // expand GEMM whose output tile is whole frames: the depthwise conv runs on the tile in LDS, E never exists
       // (flops: what this launch executes -- with `ups` the upsampled half was a GEMM at the low resolution)

@@ -50,8 +50,9 @@ struct ETile {
 // KF = floats per k-tile row: 32 (128-B rows, gemm.hip's ring) or 16 (64-B rows: half the ring, so that the whole
 // working set of a workgroup stays near the 32 KB of the 64x64 GEMM tiles it shares the CUs with -- a workgroup that
 // fills a CU's LDS shuts the other lane's kernels out, measured -2 % end to end with 74 KB rings)
-template <int HW, int F, int BN, int KF, int S = 1>
+template <int HW, int F, int BN, int KF, int S = 1, int NST_ = 2>
 struct FTGeom {
+  static constexpr int NST = NST_;                             // ring stages
   static constexpr int ROWB = KF * 4, RPI = 1024 / ROWB;       // row bytes; rows one LDS-DMA instruction fills (8 / 16)
   static constexpr int P = HW * HW, M = F * P, MT = (M + 15) / 16, M_PAD = 16 * MT;
   static constexpr int NT = BN / 16, WPN = 4 / NT;             // n-tiles; waves that share an n-tile
@@ -62,7 +63,7 @@ struct FTGeom {
   using E = ETile<HW, BN, F * HW>;                             // frame f occupies image rows f HW .. + HW - 1
   static constexpr int RS = pick_runs(NQ * HO, HO, F), RPS = (HO + RS - 1) / RS;   // runs per frame, rows per run
   static constexpr size_t etile = E::bytes;
-  static constexpr size_t lds = 2 * (size_t)STAGE > etile ? 2 * (size_t)STAGE : etile;
+  static constexpr size_t lds = NST * (size_t)STAGE > etile ? NST * (size_t)STAGE : etile;
   static constexpr int occ = (int)(160 * 1024 / lds) >= 4 ? 4 : (int)(160 * 1024 / lds);
   static_assert(NT == 2 || NT == 4, "BN = 32 or 64");
   static_assert(KF == 16 || KF == 32, "64-B or 128-B k-tile rows");
@@ -141,14 +142,9 @@ __device__ __forceinline__ void pw_dw_gemm(char* ring, const float* __restrict__
 #pragma unroll
   for (int i = 0; i < G::MTW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  issue(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of k-tile kt has landed
-    __syncthreads();                                   // ... everyone's; and everyone is done reading the other stage
-    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-    const char* st = ring + (kt & 1) * G::STAGE;
-    // all fragments of the k-tile are requested up front, then the MFMAs run back to back: s outer, tile inner, so an
-    // accumulator is reused only every MTW instructions (no dependent-issue stalls)
+  // the MFMAs of one k-tile: all its fragments are requested up front, then the MFMAs run back to back: s outer, tile
+  // inner, so an accumulator is reused only every MTW instructions (no dependent-issue stalls)
+  auto compute = [&](const char* st) __attribute__((always_inline)) {
     f32x4 fw[KF / 16], fa[KF / 16][G::MTW];
 #pragma unroll
     for (int g = 0; g < KF / 16; ++g) {
@@ -166,6 +162,31 @@ __device__ __forceinline__ void pw_dw_gemm(char* ring, const float* __restrict__
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < G::MTW; ++i) acc[i] = mfma16(fw[g][s], fa[g][i][s], acc[i]);
+  };
+  if constexpr (G::NST == 2) {
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of k-tile kt has landed
+      __syncthreads();                                   // ... everyone's; and everyone is done reading the other stage
+      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+      compute(ring + (kt & 1) * G::STAGE);
+    }
+  } else {
+    // Deep ring (round 5, small batches): NST - 1 k-tiles in flight.  With a handful of workgroups per CU nobody hides a
+    // k-tile's fill latency (two stages: ~0.45 us per k-iteration at M = 800 whatever the tile, profiles/r4_ab_small_batch.txt);
+    // here a fill has NST - 2 iterations to arrive.  Still ONE barrier per k-tile: k-tile kt + NST - 1 goes into the stage
+    // that k-tile kt - 1 was read from, and everyone has left iteration kt - 1 once they meet at the barrier of iteration kt.
+    constexpr int NST = G::NST;
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p)
+      if (p < nk) issue(p, p);
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + NST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * G::LPT) : "memory");   // k-tile kt landed (newer ones may fly)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + NST - 1 < nk) issue(kt + NST - 1, (kt + NST - 1) % NST);
+      compute(ring + (kt % NST) * G::STAGE);
+    }
   }
   __syncthreads();   // the ring is consumed: it becomes the E tile
 }
@@ -206,12 +227,12 @@ __device__ __forceinline__ void dw_run(const float* sE, int R0, int ox, int cq, 
   }
 }
 
-template <int HW, int F, int BN, int KF, int S>
-__global__ __launch_bounds__(256, (FTGeom<HW, F, BN, KF, S>::occ)) void pw_dw_kernel(
+template <int HW, int F, int BN, int KF, int S, int NST = 2>
+__global__ __launch_bounds__(256, (FTGeom<HW, F, BN, KF, S, NST>::occ)) void pw_dw_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W1, const float* __restrict__ b1,
     const float* __restrict__ wd, const float* __restrict__ bd, float* __restrict__ D, int ldd, int frames, int K, int N,
     int n_ntiles, int nwg, unsigned a_bytes, unsigned w_bytes, const float* __restrict__ ups, int ld_ups) {
-  using G = FTGeom<HW, F, BN, KF, S>;
+  using G = FTGeom<HW, F, BN, KF, S, NST>;
   using E = typename G::E;
   constexpr int ROWB = G::ROWB, RPI = G::RPI, CPR = ROWB / 16;   // 16-B columns per row
   extern __shared__ __attribute__((aligned(16))) char ring[];
@@ -306,6 +327,7 @@ __global__ __launch_bounds__(256, (FTGeom<HW, F, BN, KF, S>::occ)) void pw_dw_ke
 // else is pw_dw_kernel.
 template <int HW, int SR, int STRIDE, int BN, int KF>
 struct FSGeom {
+  static constexpr int NST = 2;
   static constexpr int ROWB = KF * 4, RPI = 1024 / ROWB;
   static constexpr int P = HW * HW, RIN = (SR - 1) * STRIDE + 3, M = RIN * HW, MT = (M + 15) / 16, M_PAD = 16 * MT;
   static constexpr int HO = (HW + 2 - 3) / STRIDE + 1, NS = (HO + SR - 1) / SR;   // output rows / strips per frame
@@ -434,11 +456,11 @@ int launch_fs(const float* a, int lda, const float* w1, const float* b1, const f
   return CASYNC_OK;
 }
 
-template <int HW, int F, int BN, int KF, int S>
+template <int HW, int F, int BN, int KF, int S, int NST = 2>
 int launch_ft(const float* a, int lda, const float* w1, const float* b1, const float* wd, const float* bd, float* d, int ldd,
               int frames, int k, int n, const float* ups, int ld_ups, hipStream_t stream) {
-  using G = FTGeom<HW, F, BN, KF, S>;
-  auto kern = pw_dw_kernel<HW, F, BN, KF, S>;
+  using G = FTGeom<HW, F, BN, KF, S, NST>;
+  auto kern = pw_dw_kernel<HW, F, BN, KF, S, NST>;
   static unsigned long long attr_once = 0;
   constexpr bool UPS_OK = F == 1 && BN == 32 && (HW / 2) * (HW / 2) * 128 <= kUpsTileBytes && G::lds % 16 == 0;   // (20x20: 12.8 KB)
   CASYNC_REQUIRE(!ups || UPS_OK, "pw_dw: no upsampled addend for %dx%d tiles of %d frames", HW, HW, F);
@@ -461,12 +483,18 @@ bool pw_dw_supported(int hw, int cin, int cexp, int stride) {
   return (hw == 20 || hw == 40) && (stride == 1 || stride == 2);
 }
 
+// the deep-ring instances serve launches of 2 .. `fuse_dw_deep` - 1 frames (10x10 / 16x16, stride 1, no upsampled addend):
+// measured B=4 -1.2 %, B=8 -2.3 %; B=1 +1.1 %, B=11 +1.4 % (profiles/r5_ab_small_batch.txt)
+static bool pw_dw_deep(int hw, int frames, int stride, bool ups) {
+  return hw <= 16 && stride == 1 && !ups && frames >= 2 && frames < casync_opts().fuse_dw_deep;
+}
+
 const char* pw_dw_kernel_name(int hw, int cexp, int frames, int stride) {
   static thread_local char buf[64];
   (void)cexp;
-  (void)frames;
   if (hw == 40) snprintf(buf, sizeof(buf), "pw_dw_strip_kernel<40, %d, %d, 32, 16>", stride == 1 ? 8 : 4, stride);
-  else snprintf(buf, sizeof(buf), "pw_dw_kernel<%d, %d, 32, 16, %d>", hw, hw == 10 ? 2 : 1, stride);
+  else if (pw_dw_deep(hw, frames, stride, false)) snprintf(buf, sizeof(buf), "pw_dw_kernel<%d, 1, 32, 32, 1, %d>", hw, hw == 10 ? 4 : 3);
+  else snprintf(buf, sizeof(buf), "pw_dw_kernel<%d, %d, 32, 16, %d, 2>", hw, hw == 10 ? 2 : 1, stride);
   return buf;
 }
 
@@ -488,8 +516,15 @@ int launch_pw_dw(const void* a, int lda, const void* w1, const float* b1, const 
   if (hw == 40)   // strips of 8 (stride 2: 4) output rows: 57 KB of LDS (10 / 5 rows: 65 KB, measured equal)
     return stride == 1 ? launch_fs<40, 8, 1, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream)
                        : launch_fs<40, 4, 2, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);
-  if (hw == 10) return launch_ft<10, 2, 32, 16, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);
-  if (hw == 16) return launch_ft<16, 1, 32, 16, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);
-  return stride == 1 ? launch_ft<20, 1, 32, 16, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream)
-                     : launch_ft<20, 1, 32, 16, 2>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);
+  // small launches (round 5): one frame per tile, 128-B k-tile rows and a four-stage (16x16: three-stage) ring -- twice
+  // the workgroups, half the k-iterations, three k-tiles in flight
+  const bool deep = pw_dw_deep(hw, frames, stride, ups != nullptr);
+  if (hw == 10)
+    return deep ? launch_ft<10, 1, 32, 32, 1, 4>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream)
+                : launch_ft<10, 2, 32, 16, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);
+  if (hw == 16)
+    return deep ? launch_ft<16, 1, 32, 32, 1, 3>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream)
+                : launch_ft<16, 1, 32, 16, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);
+  if (stride == 1) return launch_ft<20, 1, 32, 16, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);
+  return launch_ft<20, 1, 32, 16, 2>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);
 }
