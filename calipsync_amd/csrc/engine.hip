@@ -92,7 +92,7 @@ struct Layout {
 const Layout& layout() {
   static const Layout L = [] {
     Layout l;
-    l.add("inc.inconv.0.fused", 620);  // [w1 12x6][b1 12][wd 9x12][bd 12][w2 32x12][b2 32]
+    l.add("inc.inconv.0.fused", 620);  // [w1T 6x12][b1 12][wd 9x12][bd 12][w2T 12x32][b2 32]
     for (auto& st : kDown)
       for (auto& b : st) l.add_ir(b);
     l.add_ir(kAudio[0]);

@@ -9,23 +9,29 @@
 //
 // Workgroup = TH x 16 output pixels of one frame (TH = 8 stride 1, 4 stride 2), 4 waves.
 //   once:       each wave loads the MFMA A-fragments of ITS halo rows (input tile + 1-pixel halo,
-//               zeros outside the image) straight from HBM into registers; they are reused by
-//               every chunk, so the input tile never occupies LDS
+//               zeros outside the image) straight from HBM into registers (buffer-addressed: 32-bit lane offsets, a
+//               pixel outside the image is an offset past the end of the frame and reads as zeros); they are reused
+//               by every chunk, so the input tile never occupies LDS
 //   per CC-channel chunk of the expanded tensor:
-//     P1  E[hp][CC]  = mask * lrelu(A[hp][:] . W1c^T + b1)    v_mfma_f32_16x16x4_f32
-//     P2  D[p][CC]   = lrelu(dw3x3(E) + bd)                    VALU, LDS b128 reads
-//     P3  acc[p][:] += D[p][:] . W2c^T                         v_mfma_f32_16x16x4_f32
-//   end:        + b2, LReLU, (+ x from the LDS tile), coalesced NHWC store.
+//     P1  E[hp][CC]  = mask * lrelu(A[hp][:] . W1c^T + b1)    v_mfma_f32_16x16x4_f32 -> E in LDS (double buffered)
+//     P2  D[p][CC]   = lrelu(dw3x3(E) + bd)                    VALU, LDS b128 reads -> stays in REGISTERS
+//     P3  acc[p][:] += D[p][:] . W2c^T                         v_mfma_f32_16x16x4_f32, D = its B operand as P2 left it
+//   end:        + b2, LReLU, (+ x of the tile's centre pixels, parked in LDS from the A fragments), buffer-addressed
+//               stores straight from the accumulators (16 pixels x 64 B per instruction).
 // The depthwise conv zero-pads the EXPANDED tensor, so halo positions outside the image are
 // forced to 0 after the expand (border tiles only), not lrelu(b1).
 //
-// Pipeline: the next chunk's weights are fetched into registers while the current chunk
-// computes and parked in the other half of a double-buffered LDS weight area, so a chunk costs
-// two barriers (after P1, after P2) and no exposed global-load latency.  LDS tiles carry no
-// padding; 16-B columns are XOR-swizzled by row (xs()) so the b128 fragment reads of 16
-// different rows land on different banks.  With A in registers a workgroup needs ~35 KB of
-// LDS, so 3-4 of them share a CU: that is what overlaps one group's VALU/LDS phases (P2,
-// staging, epilogue) with the others' MFMA phases.
+// Pipeline (round 4): ONE workgroup barrier per chunk.  The only thing the four waves exchange is E; a barrier interval
+// is  stage | P2(c-1) | P3(c-1) | P1(c) | barrier  -- a wave runs depthwise -> project -> next expand (40-64 MFMAs back to
+// back) without meeting anybody.  Everything a chunk needs besides the A fragments goes HBM / L2 -> LDS by LDS-DMA
+// (global_load_lds, 16 B per lane, no staging registers, no ds_write) a whole interval ahead of its first use: W1c one
+// chunk ahead of W2c / Wd / bd (two groups, each double buffered), the G slice of the commuted upsample; b1 is one 16-B
+// load per lane and chunk.  LDS tiles carry no padding; 16-B columns are XOR-swizzled by row (xs(), e_off()) and the
+// permutation is applied on the SOURCE address of the LDS-DMA.  With A in registers a workgroup needs ~35 KB of LDS, so
+// 3-4 of them share a CU: that is what overlaps one group's VALU / LDS phases with the others' MFMA phases.
+// Round 5: the lane's halo coordinates are worked out once (tile index in a scalar register) and every global access is
+// a buffer access with a 32-bit offset -- prologue + epilogue were half of all vector instructions of the four-chunk
+// blocks, each of them fp32-MFMA time lost on its SIMD (753 -> 640 per wave on up3.1 / up4.1).
 //
 // MFMA 16x16x4 f32 operand maps: lane l supplies A[i = l&15][k = l>>4], B[k = l>>4][j = l&15];
 // C/D: col = l&15, row = 4*(l>>4) + reg.  Fragments are read with one ds_read_b128 per four

@@ -347,27 +347,48 @@ __global__ __launch_bounds__(256) void pred_to_u8_kernel(const float* __restrict
 // Block = 8 rows x 32 columns of one frame.  Phase A: 1x1 expand (+bias, LReLU) of the
 // 10 x 34 halo into LDS, zero where the halo leaves the image (the depthwise conv pads the
 // EXPANDED tensor with zeros).  Phase B: depthwise 3x3 from LDS, LReLU, 1x1 project,
-// LReLU.  Phase C: coalesced NHWC write through LDS.  packed = [w1 12x6][b1 12][wd 9x12]
-// [bd 12][w2 32x12][b2 32].
+// LReLU.  Phase C: coalesced NHWC write through LDS.
+// packed = [w1T 6x12][b1 12][wd 9x12][bd 12][w2T 12x32][b2 32]: both 1x1 weights are stored INPUT-channel major, so the
+// weights of two adjacent output channels are one aligned 8-byte pair.
+// Round 5: the kernel is bound by vector-instruction issue (profiles/r4_mfma_busy_bf16_b512.json: 108 M instructions per
+// 256-frame launch = 0.73 of its cycles; 2.2 TB/s), so all three stages work on channel PAIRS with packed fp32 FMAs
+// (v_pk_fma_f32: the weight pair is a scalar register pair, the activation is broadcast by op_sel) -- 590 FMAs per pixel
+// become ~300 instructions -- and E is stored as pairs (8-byte LDS accesses).  The tiles of a frame are handed to ONE
+// XCD in order (xcd_run below): x-adjacent tiles share the 128-B lines their halo columns straddle, and with the default
+// round-robin dispatch every one of them fetched those lines into a different L2 (fetch 3.2 x the input bytes).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int INC_TW = 32, INC_TH = 8, INC_HW = 160;
 constexpr int INC_HALO_W = INC_TW + 2, INC_HALO_H = INC_TH + 2, INC_HALO = INC_HALO_W * INC_HALO_H;
+constexpr int INC_TX = INC_HW / INC_TW, INC_TY = INC_HW / INC_TH, INC_TILES = INC_TX * INC_TY;
+
+__device__ __forceinline__ f32x2 lrelu2(f32x2 v) {
+  const f32x2 s = v * CASYNC_LRELU_SLOPE;
+  return f32x2{fmaxf(v.x, s.x), fmaxf(v.y, s.y)};
+}
+// workgroups b, b + 8, ... share an XCD: give each XCD a contiguous run of the launch's tiles
+__device__ __forceinline__ int xcd_run(int t, int nwg) {
+  const int qn = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
+  return (xcd < r ? xcd * (qn + 1) : r * (qn + 1) + (xcd - r) * qn) + idx;
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void inc_kernel(const float* __restrict__ x,
                                                   const float* __restrict__ packed,
-                                                  T* __restrict__ out, int ldc) {
-  __shared__ float E[INC_CEXP][INC_HALO + 4];
+                                                  T* __restrict__ out, int ldc, int nwg) {
+  __shared__ f32x2 E[INC_CEXP / 2][INC_HALO + 2];
   __shared__ float O[256][INC_COUT + 1];
-  // the 620 weights are read with uniform addresses straight from memory: scalar loads into SGPRs that the FMAs take
-  // as operands -- staged in LDS they cost ~500 (broadcast) LDS reads per pixel, as many as the kernel has FMAs
+  // the 620 weights are read with uniform addresses straight from memory: scalar loads into SGPR pairs that the packed
+  // FMAs take as operands
   const int tid = threadIdx.x;
-  const float* w1 = packed;
-  const float* b1 = packed + 72;
-  const float* wd = packed + 84;
-  const float* bd = packed + 192;
-  const float* w2 = packed + 204;
-  const float* b2 = packed + 588;
-  const int b = blockIdx.z, ty0 = blockIdx.y * INC_TH, tx0 = blockIdx.x * INC_TW;
+  const f32x2* w1 = reinterpret_cast<const f32x2*>(packed);          // [6 ci][6 pairs of ce]
+  const f32x2* b1 = reinterpret_cast<const f32x2*>(packed + 72);
+  const f32x2* wd = reinterpret_cast<const f32x2*>(packed + 84);     // [9 taps][6 pairs]
+  const f32x2* bd = reinterpret_cast<const f32x2*>(packed + 192);
+  const f32x2* w2 = reinterpret_cast<const f32x2*>(packed + 204);    // [12 ce][16 pairs of co]
+  const f32x2* b2 = reinterpret_cast<const f32x2*>(packed + 588);
+  const int bid = xcd_run(blockIdx.x, nwg);
+  const int b = bid / INC_TILES, t = bid - b * INC_TILES;
+  const int ty0 = (t / INC_TX) * INC_TH, tx0 = (t % INC_TX) * INC_TW;
   const float* xb = x + (size_t)b * INC_CIN * INC_HW * INC_HW;
   for (int p = tid; p < INC_HALO; p += 256) {
     const int hy = p / INC_HALO_W, hx = p - hy * INC_HALO_W;
@@ -378,32 +399,37 @@ __global__ __launch_bounds__(256) void inc_kernel(const float* __restrict__ x,
     for (int ci = 0; ci < INC_CIN; ++ci)
       v[ci] = inside ? xb[((size_t)ci * INC_HW + iy) * INC_HW + ix] : 0.f;
 #pragma unroll
-    for (int ce = 0; ce < INC_CEXP; ++ce) {
-      float s = b1[ce];
+    for (int cp = 0; cp < INC_CEXP / 2; ++cp) {
+      f32x2 s2 = b1[cp];
 #pragma unroll
-      for (int ci = 0; ci < INC_CIN; ++ci) s += w1[ce * INC_CIN + ci] * v[ci];
-      E[ce][p] = inside ? lrelu(s) : 0.f;
+      for (int ci = 0; ci < INC_CIN; ++ci) s2 = __builtin_elementwise_fma(w1[ci * (INC_CEXP / 2) + cp], f32x2{v[ci], v[ci]}, s2);
+      E[cp][p] = inside ? lrelu2(s2) : f32x2{0.f, 0.f};
     }
   }
   __syncthreads();
   const int ly = tid >> 5, lx = tid & 31;
-  float d[INC_CEXP];
+  f32x2 d[INC_CEXP / 2];
 #pragma unroll
-  for (int ce = 0; ce < INC_CEXP; ++ce) {
-    float s = bd[ce];
+  for (int cp = 0; cp < INC_CEXP / 2; ++cp) {
+    f32x2 s2 = bd[cp];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx)
-        s += wd[(ky * 3 + kx) * INC_CEXP + ce] * E[ce][(ly + ky) * INC_HALO_W + lx + kx];
-    d[ce] = lrelu(s);
+        s2 = __builtin_elementwise_fma(wd[(ky * 3 + kx) * (INC_CEXP / 2) + cp], E[cp][(ly + ky) * INC_HALO_W + lx + kx], s2);
+    d[cp] = lrelu2(s2);
   }
 #pragma unroll
-  for (int co = 0; co < INC_COUT; ++co) {
-    float s = b2[co];
+  for (int op = 0; op < INC_COUT / 2; ++op) {
+    f32x2 s2 = b2[op];
 #pragma unroll
-    for (int ce = 0; ce < INC_CEXP; ++ce) s += w2[co * INC_CEXP + ce] * d[ce];
-    O[tid][co] = lrelu(s);
+    for (int cp = 0; cp < INC_CEXP / 2; ++cp) {
+      s2 = __builtin_elementwise_fma(w2[(2 * cp) * (INC_COUT / 2) + op], f32x2{d[cp].x, d[cp].x}, s2);
+      s2 = __builtin_elementwise_fma(w2[(2 * cp + 1) * (INC_COUT / 2) + op], f32x2{d[cp].y, d[cp].y}, s2);
+    }
+    s2 = lrelu2(s2);
+    O[tid][2 * op] = s2.x;
+    O[tid][2 * op + 1] = s2.y;
   }
   __syncthreads();
 #pragma unroll
@@ -613,11 +639,12 @@ int launch_inc(const float* x_nchw, const float* packed_inc, void* out, int ldc,
                hipStream_t stream, int dtype) {
   CASYNC_REQUIRE(x_nchw && packed_inc && out && batch > 0 && ldc >= INC_COUT && ldc % 4 == 0,
                  "inc: bad args");
-  CASYNC_REQUIRE(batch <= 65535, "inc: batch %d > 65535 (grid.z)", batch);
-  const dim3 grid(INC_HW / INC_TW, INC_HW / INC_TH, batch);
+  CASYNC_REQUIRE(batch <= (1 << 20), "inc: batch %d", batch);
+  CASYNC_REQUIRE(((uintptr_t)packed_inc % 8) == 0, "inc: the packed weights must be 8-B aligned");
+  const int nwg = batch * INC_TILES;
   DT_DISPATCH(dtype,
-              hipLaunchKernelGGL(inc_kernel<float>, grid, dim3(256), 0, stream, x_nchw, packed_inc, (float*)out, ldc),
-              hipLaunchKernelGGL(inc_kernel<bf16_t>, grid, dim3(256), 0, stream, x_nchw, packed_inc, (bf16_t*)out, ldc));
+              hipLaunchKernelGGL(inc_kernel<float>, dim3(nwg), dim3(256), 0, stream, x_nchw, packed_inc, (float*)out, ldc, nwg),
+              hipLaunchKernelGGL(inc_kernel<bf16_t>, dim3(nwg), dim3(256), 0, stream, x_nchw, packed_inc, (bf16_t*)out, ldc, nwg));
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }

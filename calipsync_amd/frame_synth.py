@@ -59,10 +59,22 @@ def _imread(path: str, gray: bool = False) -> Optional[np.ndarray]:
 
 class FrameSynthesizer:
     def __init__(self, unet_checkpoint: Optional[str], data_dir: str, device: str = "cuda:0", batch_size: int = 8, *,
-                 seed: Optional[int] = None, precision: str = "fp32", net: Optional[Model] = None):
+                 seed: Optional[int] = None, precision: str = "fp32", net: Optional[Model] = None,
+                 batches_in_flight: Optional[int] = None):
         """Same positional arguments as the reference (infer_api.py:13-14).  Keyword-only extensions:
         ``seed`` (reproducible frame walk), ``precision`` (engine storage type), ``net`` (an already
-        loaded ``Model`` instead of a checkpoint path)."""
+        loaded ``Model`` instead of a checkpoint path), ``batches_in_flight`` (default 1, or the
+        ``CASYNC_BATCHES_IN_FLIGHT`` environment variable): how many enqueued batches ``iterate_synthesized_frames``
+        leaves on the GPU while it LOADS the next one.  1 hides the per-batch file I/O (JPEG decode + ``np.loadtxt`` of
+        ``batch_size`` frames, the reference's ``_load_batch_frames``) behind the device work; 0 is the reference's own
+        batch-by-batch order.  With frames already in memory there is nothing to hide, and on a small host share the
+        queued batch's host copies compete with the one being collected: ``bench.py``'s synthetic ``e2e`` block
+        measures both (4.4-4.5 k with one in flight, 4.8-4.9 k batch by batch on 16 cores) -- pick 0 there."""
+        if batches_in_flight is None:
+            batches_in_flight = int(os.environ.get("CASYNC_BATCHES_IN_FLIGHT", "1"))
+        if batches_in_flight < 0:
+            raise ValueError("batches_in_flight must be >= 0")
+        self.batches_in_flight = batches_in_flight
         self.device = device
         self.data_dir = data_dir
         self.batch_size = batch_size
@@ -185,8 +197,8 @@ class FrameSynthesizer:
                     if not is_generate_sync_frame:      # pass-through mode: the stored frames, numbered
                         yield from self._emit(batch_images, frame_sequence)
                         continue
-                    # one batch in flight: batch k+1 is loaded, cropped and enqueued while the GPU works on
-                    # batch k, whose frames are yielded afterwards -- same frames, same order
+                    # `batches_in_flight` (default 1): batch k+1 is loaded, cropped and enqueued while the GPU works on
+                    # batch k, whose frames are yielded afterwards -- same frames, same order; 0 = collect each batch at once
                     t0 = time.time()
                     # masks are named by their file (frame number modulo the clip): each is uploaded once and stays
                     # on the device while the walk comes back to it
@@ -195,7 +207,7 @@ class FrameSynthesizer:
                         mask_keys=[(self.data_dir, f % self.total_frames) for f in frame_sequence])
                     in_flight.append((pending, originals, frame_sequence))
                     time_stats["process_batch"] += time.time() - t0
-                    if len(in_flight) > 1:
+                    while len(in_flight) > self.batches_in_flight:
                         yield from self._drain_one(in_flight, time_stats)
                 except Exception as exc:        # a failed batch is skipped, the iterator goes on (:429-436)
                     print(f"batch starting at {batch_start} failed: {exc!r}")

@@ -65,10 +65,12 @@ def fold(sd: Mapping) -> Dict[str, np.ndarray]:
         if b.prefix == "inc.inconv.0":
             tmp: Dict[str, np.ndarray] = {}
             _fold_ir(sd, b, tmp)
+            # both 1x1 weights INPUT-channel major ([cin][cout]): the weights of two adjacent output channels are one
+            # aligned pair, the operand of the kernel's packed FMAs (ops.hip, inc_kernel)
             out["inc.inconv.0.fused"] = np.concatenate([
-                tmp[f"{b.prefix}.pw1.w"].reshape(-1), tmp[f"{b.prefix}.pw1.b"],
+                np.ascontiguousarray(tmp[f"{b.prefix}.pw1.w"].T).reshape(-1), tmp[f"{b.prefix}.pw1.b"],
                 tmp[f"{b.prefix}.dw.w"].reshape(-1), tmp[f"{b.prefix}.dw.b"],
-                tmp[f"{b.prefix}.pw2.w"].reshape(-1), tmp[f"{b.prefix}.pw2.b"]])
+                np.ascontiguousarray(tmp[f"{b.prefix}.pw2.w"].T).reshape(-1), tmp[f"{b.prefix}.pw2.b"]])
         else:
             _fold_ir(sd, b, out)
     # Up blocks (module/unet.py:90-96): x = cat([up(lo), skip]).  The bilinear upsample is linear per channel and the

@@ -80,7 +80,10 @@ def test_golden_b_intermediates(net_b, golden_b, name):
     else:
         ref, got = golden_b[f"{name}.samples"], t.reshape(-1)[sample_indices(t.size)]
     d = np.abs(got - ref).max() / max(1.0, float(np.abs(ref).max()))
-    assert d < 2e-5, (name, d)
+    # 3e-5: this fixture's audio features are x4, so the attention taps carry the largest fp32 summation-order noise of
+    # the net -- with the round-5 plan at B = 3 (one-frame expand + depthwise tiles, whole K in order) att2 sits at 2.1e-5
+    # where round 4's K-split GEMM tile had it just under 2e-5; the output bar (5e-5 absolute) is unchanged
+    assert d < 3e-5, (name, d)
 
 
 @pytest.mark.parametrize("batch", [1, 3, 5, 8, 12, 16, 24, 31, 64])
@@ -173,7 +176,9 @@ def test_frames_independent_and_batch_invariant(net):
     # stream-K splits a GEMM's k range differently for different row counts: fp32 reassociation only
     assert (full[3:4] - part).abs().max() < 1e-5
     assert torch.equal(net(xt, at), full)            # and it is repeatable bit for bit
-    with options(net, gemm_streamk=0):               # plain tiles: same order per frame -> bitwise
+    # plain tiles and one kernel choice for both batch sizes (2-9 frames take the one-frame expand + depthwise tiles, a
+    # single frame the GEMM + depthwise launches): same order per frame -> bitwise
+    with options(net, gemm_streamk=0, fuse_dw_deep=0):
         assert torch.equal(net(xt, at)[3:4], net(xt[3:4].contiguous(), at[3:4].contiguous()))
 
 
