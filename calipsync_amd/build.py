@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libcasync_hip.so")
-SOURCES = ["runtime.hip", "gemm.hip", "ops.hip", "ir_fused.hip", "pw_dw.hip", "pw_dw_bf16.hip", "attention.hip", "frame_ops.hip", "engine.hip"]
+SOURCES = ["runtime.hip", "gemm.hip", "ops.hip", "ir_fused.hip", "pw_dw.hip", "pw_dw_bf16.hip", "attention.hip", "attention_bf16.hip", "frame_ops.hip", "engine.hip"]
 HEADERS = ["common.h", "ir_common.h", "pw_dw_common.h", os.path.join("..", "..", "include", "casync_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 

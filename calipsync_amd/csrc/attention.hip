@@ -191,6 +191,11 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(
 
 }  // namespace
 
+const char* cross_attention_kernel_name(int dtype) {
+  if (dtype == DT_BF16) return casync_opts().att_bf16 ? "cross_attention_bf16_kernel" : "cross_attention_kernel<__bf16>";
+  return "cross_attention_kernel<float>";
+}
+
 int launch_cross_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
                            const void* res, int ld_res, const float* gamma_dev, void* out,
                            int ld_out, int batch, hipStream_t stream, int dtype) {
@@ -200,6 +205,8 @@ int launch_cross_attention(const void* q, int ldq, const void* k, int ldk, const
                      ld_res >= CV && ld_out >= CV,
                  "cross_attention: bad leading dimensions");
   CASYNC_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0, "cross_attention: Q/K alignment");
+  if (dtype == DT_BF16 && casync_opts().att_bf16)   // the bf16 engine's own kernel: both products on bf16 matrix instructions
+    return launch_cross_attention_bf16(q, ldq, k, ldk, v, ldv, res, ld_res, gamma_dev, out, ld_out, batch, stream);
   static unsigned long long once_f32 = 0, once_bf16 = 0;
   if (int st = dtype == DT_BF16
                    ? casync_ensure_dyn_lds(&once_bf16, reinterpret_cast<const void*>(cross_attention_kernel<bf16_t>), ATT_LDS_BYTES)

@@ -106,6 +106,8 @@ struct CasyncOptions {
   int dw_lds = 1;            // CASYNC_DW_LDS: LDS-slab depthwise kernel
   int dw_lds_bytes = 32768;  // CASYNC_DW_LDS_BYTES
   int att_nz = 0;            // CASYNC_ATT_NZ: channel split of the attention kernel (0 = by batch)
+  int att_bf16 = 1;          // CASYNC_ATT_BF16: the bf16 engine's attention core on bf16 matrix instructions (attention_bf16.hip); 0 = the
+                             //   fp32-MFMA kernel of attention.hip on bf16 storage
   int kv_early = 1;          // CASYNC_KV_EARLY: the attention K/V projection GEMM runs on the audio stream beside the face encoder:
                              //   1 = in single-lane runs (small batches), 2 = always, 0 = never (between fusion MLP and attention)
 };
@@ -264,6 +266,10 @@ int launch_upsample2x(const void* in, void* out, int ldc, int batch, int h, int 
 int launch_cross_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
                            const void* res, int ld_res, const float* gamma_dev, void* out,
                            int ld_out, int batch, hipStream_t stream, int dtype = DT_F32);
+const char* cross_attention_kernel_name(int dtype);
+// the bf16 engine's attention core (attention_bf16.hip): q, k, v, res, out bf16; one workgroup per frame
+int launch_cross_attention_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* res, int ld_res,
+                                const float* gamma_dev, void* out, int ld_out, int batch, hipStream_t stream);
 int launch_nchw_to_nhwc(const float* in, void* out, int batch, int c, int hw, hipStream_t stream,
                         int dtype = DT_F32);
 int launch_crop_to_input(const unsigned char* crops, float* x, int batch, hipStream_t stream);

@@ -671,7 +671,7 @@ struct Plan {
         ldq = 64;
       }
       Ptr kv = ar[A::KV] + i * kKV;
-      r.run((p + ".attn").c_str(), kname("cross_attention_kernel").c_str(), 2.0 * M10 * 100 * (64 + 512),
+      r.run((p + ".attn").c_str(), cross_attention_kernel_name(dt()), 2.0 * M10 * 100 * (64 + 512),
             dtype_size(dt()) * (double)M10 * (64 + kKV + 1024), [&] {
         return launch_cross_attention(Qp, ldq, kv, kBlocks * kKV, kv + 64, kBlocks * kKV, P1, 576,
                                       e.W(p + ".gamma"), ar[A::AO], 512, B, r.s, dt());

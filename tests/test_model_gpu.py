@@ -278,8 +278,10 @@ def test_bf16_engine_error_is_reported_not_hidden(net_bf16, golden):
     assert d.max() > 1e-4          # it really is the bf16 path
 
 
-# measured max relative error per tap (round 2) + 25 %
-BF16_TAP_BARS = {"x1": 3.0e-3, "x5": 8.0e-3, "a": 9.6e-3, "tx": 5.5e-3, "kx": 9.8e-3, "fuse": 9.4e-3, "u4": 1.1e-2}
+# measured max relative error per tap + 25 % (round 2; u4 re-measured in round 5: the attention core on bf16 matrix
+# instructions rounds P to bf16 -- the MAX over u4 moved 9.7e-3 -> 1.11e-2 while `fuse` moved 8.4e-3 -> 6.5e-3, the B=512
+# maximum 9.5e-3 -> 8.9e-3 and every MEAN stayed where it was (1.04e-3 on the output): extreme values of rounding noise)
+BF16_TAP_BARS = {"x1": 3.0e-3, "x5": 8.0e-3, "a": 9.6e-3, "tx": 5.5e-3, "kx": 9.8e-3, "fuse": 9.4e-3, "u4": 1.4e-2}
 
 
 @pytest.mark.parametrize("name", sorted(BF16_TAP_BARS))

@@ -627,3 +627,32 @@ def test_pw_dw_fused_bf16_rejects_bad_shapes(bf16_ops):
     for hw, stride, cin, cexp in ((12, 1, 64, 128), (10, 2, 64, 128), (20, 1, 48, 128), (20, 1, 64, 96)):
         assert lib.casync_op_pw_dw(ptr(z), cin, ptr(z), ptr(zf), ptr(zf), ptr(zf), ptr(z), cexp, 1, hw, stride, cin, cexp, 0, 0, stream()) != 0
     assert lib.casync_op_pw_dw(ptr(z), 64, ptr(z), ptr(zf), ptr(zf), ptr(zf), ptr(z), 128, 1, 10, 1, 64, 128, ptr(zf), 128, stream()) != 0
+
+
+@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("b,scale", [(1, 0.5), (3, 0.5), (70, 0.5), (2, 4.0)])
+def test_cross_attention_bf16(bf16_ops, b, scale, mfma):
+    """The bf16 engine's attention core (module/unet.py:209-217): attention_bf16.hip -- both products on bf16 matrix
+    instructions, the softmax in the registers of two lanes, V read through the hardware transpose read -- and the
+    fp32-MFMA kernel on bf16 storage (att_bf16 = 0), against float64 on the SAME bf16-rounded operands.  Q / K / V are
+    column slices of wider buffers (the engine's p1q and KV rows), `scale` 4 gives peaked (near one-hot) softmax rows.
+    What is left is the bf16 rounding of P (2^-9 on weights <= 1) and of the output."""
+    lib = bf16_ops
+    g = torch.Generator().manual_seed(17 + b)
+    p1q = (torch.randn(b, 100, 576, generator=g) * scale).bfloat16()          # [ox | q]: res = columns 0..511, q = 512..575
+    kv = (torch.randn(b, 100, 2304, generator=g) * scale).bfloat16()
+    gamma = torch.tensor([-0.75])
+    q, res = p1q[:, :, 512:], p1q[:, :, :512]
+    k, v = kv[:, :, 1152:1216], kv[:, :, 1216:1728]                          # block 2's slice of the KV rows
+    att = torch.softmax(q.double() @ k.double().transpose(1, 2), -1)
+    ref = (gamma.double() * (att @ v.double()) + res.double()).float()
+    pd, kvd, gd = p1q.to(dev()), kv.to(dev()), gamma.to(dev())
+    out = torch.full((b, 100, 520), 3.0, device=dev(), dtype=torch.bfloat16)
+    with options(att_bf16=mfma):
+        ok(lib.casync_op_cross_attention(pd.data_ptr() + 512 * 2, 576, kvd.data_ptr() + 1152 * 2, 2304, kvd.data_ptr() + 1216 * 2, 2304,
+                                         ptr(pd), 576, ptr(gd), ptr(out), 520, b, stream()))
+    o = out.float().cpu()
+    assert (o[..., 512:] == 3).all()
+    err = (o[..., :512] - ref).abs()
+    top = float(ref.abs().max())
+    assert torch.isfinite(o).all() and float(err.max()) / top < 2 ** -7 and float(err.mean()) / top < 2 ** -10
