@@ -102,6 +102,8 @@ struct CasyncOptions {
   int fuse_dw_bf16 = 2;      // CASYNC_FUSE_DW_BF16: the same fusion in the bf16 engine (pw_dw_bf16.hip: 64-channel tiles, bf16 E image):
                              //   1 = 10x10 / 16x16 / 20x20 blocks, 2 = also the 40x40 strips, 0 = GEMM + depthwise launches
   int fuse_dw_bf16_bn = 128; // CASYNC_FUSE_DW_BF16_BN: channel tile of its 10x10 / 16x16 instances (64 or 128)
+  int ups_commute_bf16 = 1;  // CASYNC_UPS_COMMUTE_BF16: up1.0 / up2.0 of the bf16 engine run the upsampled half of their expand conv at the low
+                             //   resolution and pw_dw_bf16 adds its upsample (needs fuse_dw_bf16 >= 2 and >= fuse_dw_bf16_min frames per launch)
   int fuse_dw_bf16_min = 12; // CASYNC_FUSE_DW_BF16_MIN: frames per launch from which it is used
   int dw_lds = 1;            // CASYNC_DW_LDS: LDS-slab depthwise kernel
   int dw_lds_bytes = 32768;  // CASYNC_DW_LDS_BYTES
@@ -259,8 +261,10 @@ int launch_pw_dw(const void* a, int lda, const void* w1, const float* b1, const 
 // the bf16 engine's expand + depthwise kernel (pw_dw_bf16.hip): a, w1, d bf16; b1, wd, bd fp32; cin % 32 == 0, cexp % 64 == 0
 bool pw_dw_bf16_supported(int hw, int cin, int cexp, int stride);
 const char* pw_dw_bf16_kernel_name(int hw, int cexp, int frames, int stride = 1);
+// ups (optional, 20x20 / 40x40 stride 1): bf16 low-resolution addend [frames*(hw/2)^2, ld_ups], see launch_pw_dw
+bool pw_dw_bf16_takes_ups(int hw, int stride);
 int launch_pw_dw_bf16(const void* a, int lda, const void* w1, const float* b1, const float* wd, const float* bd, void* d, int ldd,
-                      int frames, int hw, int stride, int cin, int cexp, hipStream_t stream);
+                      int frames, int hw, int stride, int cin, int cexp, hipStream_t stream, const void* ups = nullptr, int ld_ups = 0);
 int launch_upsample2x(const void* in, void* out, int ldc, int batch, int h, int wdt, int c,
                       hipStream_t stream, int dtype = DT_F32);
 int launch_cross_attention(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,

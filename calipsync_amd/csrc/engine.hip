@@ -175,11 +175,16 @@ enum class UpMode {
   FusedLoad,        // ir_fused_kernel<.., UPS = 1>: bilinear taps while loading the A fragments
   Materialise       // upsample2x into the concat buffer, then the block as any other inverted residual
 };
-UpMode up_mode(const CasyncOptions& o, const IR& b0, int dtype) {
+// does the bf16 engine's expand + depthwise kernel take this block with its upsampled addend? (`batch` frames per launch)
+bool bf16_commutes(const CasyncOptions& o, const IR& b0, int batch) {
+  return o.ups_commute_bf16 && o.fuse_dw_bf16 && (b0.hw_in < 40 || o.fuse_dw_bf16 >= 2) && batch >= o.fuse_dw_bf16_min &&
+         pw_dw_bf16_takes_ups(b0.hw_in, b0.stride) && pw_dw_bf16_supported(b0.hw_in, b0.cin / 2, b0.cexp(), b0.stride);
+}
+UpMode up_mode(const CasyncOptions& o, const IR& b0, int dtype, int batch = 0) {
   const bool f32 = dtype == DT_F32;
   if (up_is_fused(o, b0)) return f32 && o.ups_commute >= 2 ? UpMode::CommuteFused : UpMode::FusedLoad;
   // a block the plain fused kernel takes (fuse_up = 0, fuse_ir = 1) keeps it: upsample first, E never leaves LDS
-  if (f32 && o.ups_commute && !ir_is_fused(o, b0)) return UpMode::CommuteUnfused;
+  if (!ir_is_fused(o, b0) && (f32 ? o.ups_commute != 0 : bf16_commutes(o, b0, batch))) return UpMode::CommuteUnfused;
   return UpMode::Materialise;
 }
 constexpr int kMinLaneBatch = 16;
@@ -493,15 +498,19 @@ struct Plan {
         return launch_pw_dw(in, ld_in, e.W(w1name), e.W(p + ".pw1.b"), e.W(p + ".dw.w"), e.W(p + ".dw.b"), e2,
                             b.cexp(), B, b.hw_in, b.stride, k_in, b.cexp(), r.s, ups.p, b.cexp());
       });
-    } else if (dt() == DT_BF16 && !ups.p && o.fuse_dw_bf16 && (b.hw_in < 40 || o.fuse_dw_bf16 >= 2) && B >= o.fuse_dw_bf16_min &&
-               pw_dw_bf16_supported(b.hw_in, k_in, b.cexp(), b.stride)) {
+    } else if (dt() == DT_BF16 && o.fuse_dw_bf16 && (b.hw_in < 40 || o.fuse_dw_bf16 >= 2) && B >= o.fuse_dw_bf16_min &&
+               pw_dw_bf16_supported(b.hw_in, k_in, b.cexp(), b.stride) && (!ups.p || pw_dw_bf16_takes_ups(b.hw_in, b.stride))) {
       // the bf16 engine's counterpart (round 5): 64-channel tiles, bf16 E image in LDS; E never reaches HBM
       r.run((p + ".pw1dw").c_str(), pw_dw_bf16_kernel_name(b.hw_in, b.cexp(), B, b.stride),
             2.0 * (m_in * (double)k_in * b.cexp() + 9.0 * m_out * b.cexp()),
             2.0 * (m_in * (double)k_in + (double)b.cexp() * k_in + (double)m_out * b.cexp()), [&] {
         return launch_pw_dw_bf16(in, ld_in, e.WG(w1name), e.W(p + ".pw1.b"), e.W(p + ".dw.w"), e.W(p + ".dw.b"), e2, b.cexp(), B,
-                                 b.hw_in, b.stride, k_in, b.cexp(), r.s);
+                                 b.hw_in, b.stride, k_in, b.cexp(), r.s, ups.p, b.cexp());
       });
+    } else if (dt() == DT_BF16 && ups.p) {
+      casync_set_error("plan: %s was planned with the commuted upsample but the bf16 expand + depthwise kernel does not take it", b.prefix);
+      r.status = CASYNC_ERR_STATE;
+      return;
     } else {
       GemmEpilogue ep1;
       ep1.act = 1;
@@ -711,7 +720,7 @@ struct Plan {
     for (int i = 0; i < 4; ++i) {
       const int cc = 2 * c;  // concat width
       const IR& b0 = kUp[i][0];
-      const UpMode mode = up_mode(o, b0, dt());
+      const UpMode mode = up_mode(o, b0, dt(), B);
       if (mode == UpMode::CommuteUnfused) {
         // upsample and 1x1 conv commute: the upsampled half of the expand conv runs on the LOW-resolution tensor
         // (a quarter of the pixels: 37.5 % of this GEMM's multiply-adds never happen), the consumer adds its bilinear
@@ -1230,8 +1239,7 @@ int casync_op_dw3x3_ups(const float* pre, const float* g, int ldg, const float* 
 int casync_op_pw_dw(const void* a, int lda, const void* w1, const float* b1, const float* wd, const float* bd, void* d, int ldd,
                     int frames, int hw, int stride, int cin, int cexp, const void* ups, int ld_ups, casync_stream stream) {
   if (g_op_dtype == DT_BF16) {
-    CASYNC_REQUIRE(!ups, "pw_dw (bf16): no upsampled addend");
-    return launch_pw_dw_bf16(a, lda, w1, b1, wd, bd, d, ldd, frames, hw, stride, cin, cexp, (hipStream_t)stream);
+    return launch_pw_dw_bf16(a, lda, w1, b1, wd, bd, d, ldd, frames, hw, stride, cin, cexp, (hipStream_t)stream, ups, ld_ups);
   }
   return launch_pw_dw(a, lda, w1, b1, wd, bd, d, ldd, frames, hw, stride, cin, cexp, (hipStream_t)stream, ups, ld_ups);
 }

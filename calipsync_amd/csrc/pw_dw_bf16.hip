@@ -160,6 +160,40 @@ __device__ __forceinline__ void e_store(char* sE, int R, int x, int ng, int q, f
   *reinterpret_cast<bf16x4*>(sE + E::at(R, x, 4 * ng + 2 + (q >> 1)) + 8 * (q & 1)) = __builtin_convertvector(v1, bf16x4);
 }
 
+// ---- the upsampled addend of an Up block's commuted expand conv (common.h GemmEpilogue::ups_src; pw_dw.hip does the same in
+// fp32): W1 . cat(up(lo), skip) = up(W1a . lo) + W1b . skip, so the tile's GEMM runs over the skip half only and epilogue 1
+// adds the bilinear x2 upsample (align_corners=True) of G = W1a . lo, whose low-resolution rows under the tile are parked
+// in LDS behind the ring / E image by LDS-DMA while the GEMM runs: GR rows of HL pixels x 64 channels (128 B per pixel,
+// 16 KB), the eight 16-B channel groups of pixel p XOR-keyed by p & 7 on the source side ----
+constexpr int kUpsTileBytes = 16384;   // 6 rows x 20 pixels (40x40 strips) or 10 x 10 (20x20 frames) x 128 B, rounded up to 4 issues
+template <int HL>
+__device__ __forceinline__ void ups_tile_load_b(char* sG, const bf16_t* g, int ld, int gy0, int n_rows, int wave, int lane) {
+  // g: this frame's channel slice (64 channels from the workgroup's n0); rows past the tile / frame re-read the last one
+#pragma unroll
+  for (int j = 0; j < kUpsTileBytes / 4096; ++j) {
+    const int piece = (j * 4 + wave) * 64 + lane, p = piece >> 3, ql = piece & 7;
+    int gr = p / HL;
+    const int gx = p - gr * HL;
+    gr = gr < n_rows ? gr : n_rows - 1;
+    const int gy = gy0 + gr < HL ? gy0 + gr : HL - 1;
+    const bf16_t* src = g + (size_t)(gy * HL + gx) * ld + 8 * (ql ^ (p & 7));
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                     (void __attribute__((address_space(3)))*)(sG + (j * 4 + wave) * 1024), 16, 0, 0);
+  }
+}
+// four channels (16-B group c8, half `half`) of up(G) at high-resolution pixel (y, x)
+template <int HW>
+__device__ __forceinline__ f32x4 ups_at_lds_b(const char* sG, int gy0, int y, int x, int c8, int half) {
+  constexpr int HL = HW / 2;
+  const UpsTap ty = ups_tap((float)(HL - 1) / (float)(HW - 1), y, HL), tx = ups_tap((float)(HL - 1) / (float)(HW - 1), x, HL);
+  auto at = [&](int gy, int gx) {
+    const int p = (gy - gy0) * HL + gx;
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(sG + p * 128 + 16 * (c8 ^ (p & 7)) + 8 * half);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  };
+  return ups_lerp(ty, tx, at(ty.i0, tx.i0), at(ty.i0, tx.i1), at(ty.i1, tx.i0), at(ty.i1, tx.i1));
+}
+
 struct Taps8 {          // nine taps + the bias of eight consecutive channels
   f32x4 w[9][2], b[2];
 };
@@ -252,7 +286,7 @@ template <int HW, int F, int BN, int S>
 __global__ __launch_bounds__(256, (FTGeomB<HW, F, BN, S>::occ)) void pw_dw_bf16_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W1, const float* __restrict__ b1,
     const float* __restrict__ wd, const float* __restrict__ bd, bf16_t* __restrict__ D, int ldd, int frames, int K, int N,
-    int n_ntiles, int nwg, unsigned a_bytes, unsigned w_bytes) {
+    int n_ntiles, int nwg, unsigned a_bytes, unsigned w_bytes, const bf16_t* __restrict__ ups, int ld_ups) {
   using G = FTGeomB<HW, F, BN, S>;
   using E = typename G::E;
   extern __shared__ __attribute__((aligned(16))) char ring[];
@@ -267,23 +301,35 @@ __global__ __launch_bounds__(256, (FTGeomB<HW, F, BN, S>::occ)) void pw_dw_bf16_
 
   int voff[G::LPT];
   dma_offsets<G>(voff, wave, lane, lda, K, n0, BN, [&](int r) { return m0 + (r < m_valid ? r : m_valid - 1); });   // pad rows re-read the last pixel
+  // the low-resolution tile of the upsampled addend travels under the GEMM (F = 1 frame, BN = 64: the whole HW/2 x HW/2 frame)
+  char* sG = ring + G::lds;
+  if (ups) ups_tile_load_b<HW / 2>(sG, ups + (size_t)f0 * (HW / 2) * (HW / 2) * ld_ups + n0, ld_ups, 0, HW / 2, wave, lane);
+  // (the expand biases are requested before the K loop and the depthwise taps before epilogue 1 -- both are the head of a
+  // latency chain otherwise: a global load in front of the first instruction that needs it)
+  const int ng = wave % G::NG, mg = wave / G::NG;
+  const f32x4 bias0 = *reinterpret_cast<const f32x4*>(b1 + n0 + 32 * ng + 4 * q);
+  const f32x4 bias1 = *reinterpret_cast<const f32x4*>(b1 + n0 + 32 * ng + 16 + 4 * q);
   f32x4 acc[G::MTW][2];
   pw_dw_gemm_b<G>(ring, A, W1, a_bytes, w_bytes, voff, K / 32, wave, l15, q, acc);
+  Taps8 taps;
+  load_taps(taps, wd, bd, n0 + 8 * (tid % G::NQ), N);   // 256 % NQ == 0: a thread keeps its channel column
 
-  // ---- epilogue 1: + b1, LeakyReLU -> the zero-bordered bf16 E image ----
+  // ---- epilogue 1: + b1 (+ the upsampled addend), LeakyReLU -> the zero-bordered bf16 E image ----
   char* sE = ring;
   e_zero_border<E, F * HW, HW>(sE, tid);
   {
-    const int ng = wave % G::NG, mg = wave / G::NG;
-    const f32x4 bias0 = *reinterpret_cast<const f32x4*>(b1 + n0 + 32 * ng + 4 * q);
-    const f32x4 bias1 = *reinterpret_cast<const f32x4*>(b1 + n0 + 32 * ng + 16 + 4 * q);
 #pragma unroll
     for (int i = 0; i < G::MTW; ++i) {
       const int t = mg + G::MG * i;
       const int px = 16 * t + l15;
       if (t < G::MT && px < m_valid) {
         const int f = px / G::P, rem = px - f * G::P, y = rem / HW, x = rem - y * HW;
-        e_store<E>(sE, f * HW + y, x, ng, q, lrelu4(acc[i][0] + bias0), lrelu4(acc[i][1] + bias1));
+        f32x4 v0 = acc[i][0] + bias0, v1 = acc[i][1] + bias1;
+        if (ups) {
+          v0 += ups_at_lds_b<HW>(sG, 0, y, x, 4 * ng + (q >> 1), q & 1);
+          v1 += ups_at_lds_b<HW>(sG, 0, y, x, 4 * ng + 2 + (q >> 1), q & 1);
+        }
+        e_store<E>(sE, f * HW + y, x, ng, q, lrelu4(v0), lrelu4(v1));
       }
     }
   }
@@ -292,15 +338,10 @@ __global__ __launch_bounds__(256, (FTGeomB<HW, F, BN, S>::occ)) void pw_dw_bf16_
   // ---- epilogue 2: depthwise 3x3 (zero columns / the zero row = the padding), + bd, LeakyReLU -> D ----
   {
     constexpr int HO = G::HO, NITEM = G::NQ * HO * G::RS * F;
-    Taps8 taps;
-    int c_of = -1;
+    static_assert(256 % G::NQ == 0, "a thread keeps its channel column");
     for (int id = tid; id < NITEM; id += 256) {
       const int c = id % G::NQ, rest = id / G::NQ, ox = rest % HO, run = rest / HO, f = run / G::RS, r0 = (run - f * G::RS) * G::RPS;
       if (f >= nf) continue;
-      if (c != c_of) {   // (256 % NQ == 0: a thread keeps its channel column; loaded once)
-        load_taps(taps, wd, bd, n0 + 8 * c, N);
-        c_of = c;
-      }
       const int nrows = HO - r0 < G::RPS ? HO - r0 : G::RPS;
       dw_run_b<E, S, HW, true, G::RPS>(sE, f * HW + r0 * S - 1, r0 * S - 1, ox, c, taps,
                                        D + ((size_t)(f0 + f) * HO * HO + (size_t)r0 * HO + ox) * ldd + n0 + 8 * c, (size_t)HO * ldd, nrows);
@@ -328,7 +369,7 @@ template <int HW, int SR, int STRIDE, int BN>
 __global__ __launch_bounds__(256, (FSGeomB<HW, SR, STRIDE, BN>::occ)) void pw_dw_bf16_strip_kernel(
     const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W1, const float* __restrict__ b1,
     const float* __restrict__ wd, const float* __restrict__ bd, bf16_t* __restrict__ D, int ldd, int frames, int K, int N,
-    int n_ntiles, int nwg, unsigned a_bytes, unsigned w_bytes) {
+    int n_ntiles, int nwg, unsigned a_bytes, unsigned w_bytes, const bf16_t* __restrict__ ups, int ld_ups) {
   using G = FSGeomB<HW, SR, STRIDE, BN>;
   using E = typename G::E;
   extern __shared__ __attribute__((aligned(16))) char ring[];
@@ -348,16 +389,22 @@ __global__ __launch_bounds__(256, (FSGeomB<HW, SR, STRIDE, BN>::occ)) void pw_dw
     const int row = row_base + r;
     return row < row_lo ? row_lo : (row > row_lo + G::P - 1 ? row_lo + G::P - 1 : row);
   });
+  // the low-resolution rows under this strip (at most 6: the tap rows of its first and last row inside the frame)
+  char* sG = ring + G::lds;
+  const int gy0 = ups_tap((float)(HW / 2 - 1) / (float)(HW - 1), y0 < 0 ? 0 : y0, HW / 2).i0;
+  if (ups) ups_tile_load_b<HW / 2>(sG, ups + (size_t)fr * (HW / 2) * (HW / 2) * ld_ups + n0, ld_ups, gy0, kUpsTileBytes / (HW / 2 * 128), wave, lane);
+  const int ng = wave % G::NG, mg = wave / G::NG;
+  const f32x4 bias0 = *reinterpret_cast<const f32x4*>(b1 + n0 + 32 * ng + 4 * q);   // (requested ahead: see pw_dw_bf16_kernel)
+  const f32x4 bias1 = *reinterpret_cast<const f32x4*>(b1 + n0 + 32 * ng + 16 + 4 * q);
   f32x4 acc[G::MTW][2];
   pw_dw_gemm_b<G>(ring, A, W1, a_bytes, w_bytes, voff, K / 32, wave, l15, q, acc);
+  Taps8 taps;
+  load_taps(taps, wd, bd, n0 + 8 * (tid % G::NQ), N);
 
-  // ---- epilogue 1: + b1, LeakyReLU -> the E image; rows outside the frame are zero ----
+  // ---- epilogue 1: + b1 (+ the upsampled addend), LeakyReLU -> the E image; rows outside the frame are zero ----
   char* sE = ring;
   e_zero_border<E, G::RIN, HW>(sE, tid);
   {
-    const int ng = wave % G::NG, mg = wave / G::NG;
-    const f32x4 bias0 = *reinterpret_cast<const f32x4*>(b1 + n0 + 32 * ng + 4 * q);
-    const f32x4 bias1 = *reinterpret_cast<const f32x4*>(b1 + n0 + 32 * ng + 16 + 4 * q);
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < G::MTW; ++i) {
@@ -366,7 +413,12 @@ __global__ __launch_bounds__(256, (FSGeomB<HW, SR, STRIDE, BN>::occ)) void pw_dw
       if (t < G::MT && px < G::M) {
         const int yl = px / HW, x = px - yl * HW, y = y0 + yl;
         const bool inside = y >= 0 && y < HW;
-        e_store<E>(sE, yl, x, ng, q, inside ? lrelu4(acc[i][0] + bias0) : z, inside ? lrelu4(acc[i][1] + bias1) : z);
+        f32x4 v0 = acc[i][0] + bias0, v1 = acc[i][1] + bias1;
+        if (ups && inside) {
+          v0 += ups_at_lds_b<HW>(sG, gy0, y, x, 4 * ng + (q >> 1), q & 1);
+          v1 += ups_at_lds_b<HW>(sG, gy0, y, x, 4 * ng + 2 + (q >> 1), q & 1);
+        }
+        e_store<E>(sE, yl, x, ng, q, inside ? lrelu4(v0) : z, inside ? lrelu4(v1) : z);
       }
     }
   }
@@ -376,15 +428,10 @@ __global__ __launch_bounds__(256, (FSGeomB<HW, SR, STRIDE, BN>::occ)) void pw_dw
   {
     constexpr int HO = G::HO, NITEM = G::NQ * HO * G::RS;
     const int oy_first = st * SR, rows_out = HO - oy_first < SR ? HO - oy_first : SR;
-    Taps8 taps;
-    int c_of = -1;
+    static_assert(256 % G::NQ == 0, "a thread keeps its channel column");
     for (int id = tid; id < NITEM; id += 256) {
       const int c = id % G::NQ, rest = id / G::NQ, ox = rest % HO, r0 = (rest / HO) * G::RPS;
       if (r0 >= rows_out) continue;
-      if (c != c_of) {
-        load_taps(taps, wd, bd, n0 + 8 * c, N);
-        c_of = c;
-      }
       const int nrows = rows_out - r0 < G::RPS ? rows_out - r0 : G::RPS;
       dw_run_b<E, STRIDE, HW, false, G::RPS>(sE, r0 * STRIDE, 0, ox, c, taps,
                                              D + (((size_t)fr * HO + oy_first + r0) * HO + ox) * ldd + n0 + 8 * c, (size_t)HO * ldd, nrows);
@@ -393,35 +440,40 @@ __global__ __launch_bounds__(256, (FSGeomB<HW, SR, STRIDE, BN>::occ)) void pw_dw
 }
 
 template <class G, class Kern>
-int launch_common(Kern kern, unsigned long long* attr_once, long long nwg, const bf16_t* a, int lda, const bf16_t* w1, const float* b1,
-                  const float* wd, const float* bd, bf16_t* d, int ldd, int frames, int k, int n, int n_nt, hipStream_t stream) {
-  if (int st = casync_ensure_dyn_lds(attr_once, reinterpret_cast<const void*>(kern), (int)G::lds)) return st;
+int launch_common(Kern kern, unsigned long long* attr_once, bool ups_ok, long long nwg, const bf16_t* a, int lda, const bf16_t* w1,
+                  const float* b1, const float* wd, const float* bd, bf16_t* d, int ldd, int frames, int k, int n, int n_nt,
+                  const bf16_t* ups, int ld_ups, hipStream_t stream) {
+  CASYNC_REQUIRE(!ups || ups_ok, "pw_dw (bf16): this instance takes no upsampled addend");
+  if (int st = casync_ensure_dyn_lds(attr_once, reinterpret_cast<const void*>(kern), (int)G::lds + (ups_ok ? kUpsTileBytes : 0))) return st;
   const unsigned long long ab = ((unsigned long long)((long long)frames * G::P - 1) * lda + k) * 2, wb = (unsigned long long)n * k * 2;
   CASYNC_REQUIRE(nwg < (1ll << 31) && ab < (1ull << 31) && wb < (1ull << 31), "pw_dw (bf16): operand larger than 2 GiB");
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), G::lds, stream, a, lda, w1, b1, wd, bd, d, ldd, frames, k, n, n_nt, (int)nwg,
-                     (unsigned)ab, (unsigned)wb);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), G::lds + (ups ? kUpsTileBytes : 0), stream, a, lda, w1, b1, wd, bd, d, ldd, frames,
+                     k, n, n_nt, (int)nwg, (unsigned)ab, (unsigned)wb, ups, ld_ups);
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }
 
 template <int HW, int SR, int STRIDE, int BN>
 int launch_fs(const bf16_t* a, int lda, const bf16_t* w1, const float* b1, const float* wd, const float* bd, bf16_t* d, int ldd,
-              int frames, int k, int n, hipStream_t stream) {
+              int frames, int k, int n, const bf16_t* ups, int ld_ups, hipStream_t stream) {
   using G = FSGeomB<HW, SR, STRIDE, BN>;
   static unsigned long long attr_once = 0;
+  constexpr bool UPS_OK = BN == 64 && STRIDE == 1 && G::lds % 16 == 0 && (HW / 2) * 128 * 6 <= kUpsTileBytes && G::lds + kUpsTileBytes <= 160 * 1024;
   const int n_nt = n / BN;
-  return launch_common<G>(pw_dw_bf16_strip_kernel<HW, SR, STRIDE, BN>, &attr_once, (long long)frames * G::NS * n_nt, a, lda, w1, b1, wd, bd, d,
-                          ldd, frames, k, n, n_nt, stream);
+  return launch_common<G>(pw_dw_bf16_strip_kernel<HW, SR, STRIDE, BN>, &attr_once, UPS_OK, (long long)frames * G::NS * n_nt, a, lda, w1, b1,
+                          wd, bd, d, ldd, frames, k, n, n_nt, ups, ld_ups, stream);
 }
 
 template <int HW, int F, int BN, int S>
 int launch_ft(const bf16_t* a, int lda, const bf16_t* w1, const float* b1, const float* wd, const float* bd, bf16_t* d, int ldd,
-              int frames, int k, int n, hipStream_t stream) {
+              int frames, int k, int n, const bf16_t* ups, int ld_ups, hipStream_t stream) {
   using G = FTGeomB<HW, F, BN, S>;
   static unsigned long long attr_once = 0;
+  constexpr bool UPS_OK = F == 1 && BN == 64 && S == 1 && HW % 2 == 0 && G::lds % 16 == 0 && (HW / 2) * (HW / 2) * 128 <= kUpsTileBytes &&
+                          G::lds + kUpsTileBytes <= 160 * 1024;
   const int n_nt = n / BN;
-  return launch_common<G>(pw_dw_bf16_kernel<HW, F, BN, S>, &attr_once, (long long)((frames + F - 1) / F) * n_nt, a, lda, w1, b1, wd, bd, d, ldd,
-                          frames, k, n, n_nt, stream);
+  return launch_common<G>(pw_dw_bf16_kernel<HW, F, BN, S>, &attr_once, UPS_OK, (long long)((frames + F - 1) / F) * n_nt, a, lda, w1, b1, wd,
+                          bd, d, ldd, frames, k, n, n_nt, ups, ld_ups, stream);
 }
 
 // channel tile of the whole-frame instances below 20x20: 64, or 128 when the option asks for it and N allows
@@ -447,8 +499,10 @@ const char* pw_dw_bf16_kernel_name(int hw, int cexp, int frames, int stride) {
   return buf;
 }
 
+bool pw_dw_bf16_takes_ups(int hw, int stride) { return stride == 1 && (hw == 20 || hw == 40); }
+
 int launch_pw_dw_bf16(const void* a, int lda, const void* w1, const float* b1, const float* wd, const float* bd, void* d, int ldd,
-                      int frames, int hw, int stride, int cin, int cexp, hipStream_t stream) {
+                      int frames, int hw, int stride, int cin, int cexp, hipStream_t stream, const void* ups, int ld_ups) {
   CASYNC_REQUIRE(a && w1 && b1 && wd && bd && d && frames > 0, "pw_dw (bf16): bad args");
   CASYNC_REQUIRE(pw_dw_bf16_supported(hw, cin, cexp, stride), "pw_dw (bf16): no instance for %dx%d cin=%d cexp=%d stride=%d", hw, hw, cin,
                  cexp, stride);
@@ -456,19 +510,22 @@ int launch_pw_dw_bf16(const void* a, int lda, const void* w1, const float* b1, c
   CASYNC_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)w1 % 16) == 0 && ((uintptr_t)d % 16) == 0 && ((uintptr_t)b1 % 16) == 0 &&
                      ((uintptr_t)wd % 16) == 0 && ((uintptr_t)bd % 16) == 0,
                  "pw_dw (bf16): pointers must be 16-B aligned");
+  CASYNC_REQUIRE(!ups || (pw_dw_bf16_takes_ups(hw, stride) && ld_ups >= cexp && ld_ups % 8 == 0 && (uintptr_t)ups % 16 == 0),
+                 "pw_dw (bf16): bad upsampled addend");
   const bf16_t* af = static_cast<const bf16_t*>(a);
   const bf16_t* wf = static_cast<const bf16_t*>(w1);
+  const bf16_t* uf = static_cast<const bf16_t*>(ups);
   bf16_t* df = static_cast<bf16_t*>(d);
   if (hw == 40)
-    return stride == 1 ? launch_fs<40, 8, 1, 64>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stream)
-                       : launch_fs<40, 4, 2, 64>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stream);
+    return stride == 1 ? launch_fs<40, 8, 1, 64>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream)
+                       : launch_fs<40, 4, 2, 64>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);
   if (hw == 20)
-    return stride == 1 ? launch_ft<20, 1, 64, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stream)
-                       : launch_ft<20, 1, 64, 2>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stream);
+    return stride == 1 ? launch_ft<20, 1, 64, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream)
+                       : launch_ft<20, 1, 64, 2>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);
   const bool wide = bn_small(cexp) == 128;
   if (hw == 10)
-    return wide ? launch_ft<10, 2, 128, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stream)
-                : launch_ft<10, 2, 64, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stream);
-  return wide ? launch_ft<16, 1, 128, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stream)
-              : launch_ft<16, 1, 64, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, stream);
+    return wide ? launch_ft<10, 2, 128, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream)
+                : launch_ft<10, 2, 64, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);
+  return wide ? launch_ft<16, 1, 128, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream)
+              : launch_ft<16, 1, 64, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);
 }

@@ -656,3 +656,36 @@ def test_cross_attention_bf16(bf16_ops, b, scale, mfma):
     err = (o[..., :512] - ref).abs()
     top = float(ref.abs().max())
     assert torch.isfinite(o).all() and float(err.max()) / top < 2 ** -7 and float(err.mean()) / top < 2 ** -10
+
+
+@pytest.mark.parametrize("hw,c_lo,cexp,frames", [(20, 256, 1024, 3), (20, 256, 1024, 17), (40, 128, 512, 2), (40, 128, 512, 5), (20, 64, 128, 1)])
+def test_up_block_expand_with_commuted_upsample_bf16(bf16_ops, hw, c_lo, cexp, frames):
+    """The first inverted residual of an Up stage in the bf16 engine (module/unet.py:90-97 then :17-30): the upsample commuted
+    behind the expand conv -- G = W1a . lo by a bf16 GEMM at the low resolution, pw_dw_bf16 runs W1b . skip and adds the
+    bilinear x2 upsample of G from an LDS tile before the LeakyReLU, then the depthwise conv -- against PyTorch in float64 in
+    the REFERENCE's order (upsample, cat, conv) on the same bf16-rounded operands.  Differences: the bf16 rounding of G (a
+    second rounding the un-commuted chain does not have), of E and of the output."""
+    lib = bf16_ops
+    g = torch.Generator().manual_seed(hw + c_lo + frames)
+    lo = torch.randn(frames, c_lo, hw // 2, hw // 2, generator=g).bfloat16()
+    skip = torch.randn(frames, c_lo, hw, hw, generator=g).bfloat16()
+    w1 = (torch.randn(cexp, 2 * c_lo, generator=g) / (2 * c_lo) ** 0.5).bfloat16()
+    b1 = torch.randn(cexp, generator=g) * 0.3
+    wd = torch.randn(cexp, 1, 3, 3, generator=g) / 3
+    bd = torch.randn(cexp, generator=g) * 0.3
+    x = torch.cat([F.interpolate(lo.double(), scale_factor=2, mode="bilinear", align_corners=True), skip.double()], 1)
+    e = F.leaky_relu(F.conv2d(x, w1.double()[:, :, None, None], b1.double()), 0.01)
+    ref = F.leaky_relu(F.conv2d(e, wd.double(), bd.double(), 1, 1, 1, cexp), 0.01).float()
+    w1a, w1b = w1[:, :c_lo].contiguous().to(dev()), w1[:, c_lo:].contiguous().to(dev())
+    lod, skd = nhwc(lo), nhwc(skip)
+    m_lo = frames * (hw // 2) ** 2
+    G = torch.empty(m_lo, cexp, device=dev(), dtype=torch.bfloat16)
+    ok(lib.casync_op_pw_gemm(ptr(lod), c_lo, ptr(w1a), 0, ptr(G), cexp, m_lo, cexp, c_lo, 0, 0, 0, 0, 0, 0, 0, 0, stream()))
+    out = torch.empty(frames, hw, hw, cexp, device=dev(), dtype=torch.bfloat16)
+    wdp, b1d, bdd = wd.reshape(cexp, 9).T.contiguous().to(dev()), b1.to(dev()), bd.to(dev())
+    ok(lib.casync_op_pw_dw(ptr(skd), c_lo, ptr(w1b), ptr(b1d), ptr(wdp), ptr(bdd), ptr(out), cexp, frames, hw, 1, c_lo, cexp,
+                           ptr(G), cexp, stream()))
+    got = out.float().permute(0, 3, 1, 2).cpu()
+    top = float(ref.abs().max())
+    err = (got - ref).abs()
+    assert float(err.max()) / top < 2 ** -6 and float(err.mean()) / top < 2 ** -10
