@@ -133,7 +133,7 @@ __device__ __forceinline__ void dma_offsets(int (&voff)[G::LPT], int wave, int l
     const int r = (j * 4 + wave) * RPI + lrow;             // row inside the stage
     const int cs = lcol ^ ft_key<16>(r);                   // swizzled source column
     if ((j * 4 + wave) * RPI < G::M_PAD) {
-      voff[j] = (int)((long long)a_row(r) * lda * 2) + cs * 16;
+      voff[j] = (int)__umul24((unsigned)a_row(r), (unsigned)(lda * 2)) + cs * 16;   // rows < 2^24, row bytes < 2^24; the operand is < 2 GiB (launcher)
     } else {
       const int wr = r - G::M_PAD < BN ? r - G::M_PAD : 0; // rows behind the tile (LPT rounds up) re-read W row 0
       voff[j] = (n0 + wr) * K * 2 + cs * 16;
@@ -181,17 +181,37 @@ __device__ __forceinline__ void ups_tile_load_b(char* sG, const bf16_t* g, int l
                                      (void __attribute__((address_space(3)))*)(sG + (j * 4 + wave) * 1024), 16, 0, 0);
   }
 }
-// four channels (16-B group c8, half `half`) of up(G) at high-resolution pixel (y, x)
+// up(G) at high-resolution pixel (y, x): the four low-resolution corners (pixel index in the tile) and their weights, worked
+// out once per pixel; then four channels (16-B group c8, half `half`) per call.  Weighted sum of the four corners with fused
+// multiply-adds (the fp32 kernels keep ATen's unfused three-lerp form so that every fp32 kernel produces the same bits; at
+// bf16 storage precision that buys nothing and costs 18 instead of 8 packed operations per four channels).
+struct UpsCorners {
+  int p[4];
+  float w[4];
+};
 template <int HW>
-__device__ __forceinline__ f32x4 ups_at_lds_b(const char* sG, int gy0, int y, int x, int c8, int half) {
+__device__ __forceinline__ UpsCorners ups_corners(int gy0, int y, int x) {
   constexpr int HL = HW / 2;
   const UpsTap ty = ups_tap((float)(HL - 1) / (float)(HW - 1), y, HL), tx = ups_tap((float)(HL - 1) / (float)(HW - 1), x, HL);
-  auto at = [&](int gy, int gx) {
-    const int p = (gy - gy0) * HL + gx;
-    const bf16x4 v = *reinterpret_cast<const bf16x4*>(sG + p * 128 + 16 * (c8 ^ (p & 7)) + 8 * half);
-    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-  };
-  return ups_lerp(ty, tx, at(ty.i0, tx.i0), at(ty.i0, tx.i1), at(ty.i1, tx.i0), at(ty.i1, tx.i1));
+  UpsCorners c;
+  c.p[0] = (ty.i0 - gy0) * HL + tx.i0;
+  c.p[1] = (ty.i0 - gy0) * HL + tx.i1;
+  c.p[2] = (ty.i1 - gy0) * HL + tx.i0;
+  c.p[3] = (ty.i1 - gy0) * HL + tx.i1;
+  c.w[0] = ty.l0 * tx.l0;
+  c.w[1] = ty.l0 * tx.l1;
+  c.w[2] = ty.l1 * tx.l0;
+  c.w[3] = ty.l1 * tx.l1;
+  return c;
+}
+__device__ __forceinline__ f32x4 ups_at_lds_b(const char* sG, const UpsCorners& c, int c8, int half) {
+  f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(sG + c.p[k] * 128 + 16 * (c8 ^ (c.p[k] & 7)) + 8 * half);
+    r += c.w[k] * f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  }
+  return r;
 }
 
 struct Taps8 {          // nine taps + the bias of eight consecutive channels
@@ -326,8 +346,9 @@ __global__ __launch_bounds__(256, (FTGeomB<HW, F, BN, S>::occ)) void pw_dw_bf16_
         const int f = px / G::P, rem = px - f * G::P, y = rem / HW, x = rem - y * HW;
         f32x4 v0 = acc[i][0] + bias0, v1 = acc[i][1] + bias1;
         if (ups) {
-          v0 += ups_at_lds_b<HW>(sG, 0, y, x, 4 * ng + (q >> 1), q & 1);
-          v1 += ups_at_lds_b<HW>(sG, 0, y, x, 4 * ng + 2 + (q >> 1), q & 1);
+          const UpsCorners uc = ups_corners<HW>(0, y, x);
+          v0 += ups_at_lds_b(sG, uc, 4 * ng + (q >> 1), q & 1);
+          v1 += ups_at_lds_b(sG, uc, 4 * ng + 2 + (q >> 1), q & 1);
         }
         e_store<E>(sE, f * HW + y, x, ng, q, lrelu4(v0), lrelu4(v1));
       }
@@ -415,8 +436,9 @@ __global__ __launch_bounds__(256, (FSGeomB<HW, SR, STRIDE, BN>::occ)) void pw_dw
         const bool inside = y >= 0 && y < HW;
         f32x4 v0 = acc[i][0] + bias0, v1 = acc[i][1] + bias1;
         if (ups && inside) {
-          v0 += ups_at_lds_b<HW>(sG, gy0, y, x, 4 * ng + (q >> 1), q & 1);
-          v1 += ups_at_lds_b<HW>(sG, gy0, y, x, 4 * ng + 2 + (q >> 1), q & 1);
+          const UpsCorners uc = ups_corners<HW>(gy0, y, x);
+          v0 += ups_at_lds_b(sG, uc, 4 * ng + (q >> 1), q & 1);
+          v1 += ups_at_lds_b(sG, uc, 4 * ng + 2 + (q >> 1), q & 1);
         }
         e_store<E>(sE, yl, x, ng, q, inside ? lrelu4(v0) : z, inside ? lrelu4(v1) : z);
       }
