@@ -706,50 +706,59 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
   };
 
   wload(0);
-  // ---- A fragments of this wave's halo rows: HBM -> registers, once ----
+  // ---- A fragments of this wave's halo rows: HBM -> registers, once.  Round 5: the tile index is a scalar (wave_s), every
+  //      access is a buffer access with a 32-bit lane offset (a pixel outside the image = an offset past the end = zeros), and
+  //      the on-the-fly bilinear x2 of the Up blocks is a weighted sum of its four corners with packed fused multiply-adds
+  //      (corner weights once per pixel) -- the prologue was 848 of ~2,000 vector instructions per wave in up4.0 ----
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  constexpr unsigned kOob = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(inb), 0, (unsigned)H * W * ld_in * 2u, 0x00020000);
   bf16x8 fa[G::MT1][GB::KG];
-  const bf16x8 zero8 = __builtin_bit_cast(bf16x8, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
   for (int i = 0; i < G::MT1; ++i) {
     int hy, hx;   // the fp32 kernel's halo walk: tiles never straddle a halo row (what e_off() is conflict free for)
-    const bool live = halo_px<G>(wave * G::MT1 + i, l15, hy, hx);
+    const bool live = halo_px<G>(wave_s * G::MT1 + i, l15, hy, hx);
     const int iy = iy0 + hy, ix = ix0 + hx;
-    const bool ok = live && iy >= 0 && iy < H && ix >= 0 && ix < W;
-    const bf16_t* src = inb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * ld_in + 8 * q;
+    const bool ok = live && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const unsigned aoff = ok ? (unsigned)(((iy * W + ix) * ld_in + 8 * q) * 2) : kOob;
     if constexpr (UPS) {
       const int Hl = H >> 1, Wl = W >> 1;
+      const __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(lo + (size_t)b * Hl * Wl * ld_lo), 0,
+                                                                               (unsigned)Hl * Wl * ld_lo * 2u, 0x00020000);
       const float sy = (float)(Hl - 1) / (float)(H - 1), sx = (float)(Wl - 1) / (float)(W - 1);
       const float fy = sy * (ok ? iy : 0), fx = sx * (ok ? ix : 0);
       const int y0 = (int)fy, x0 = (int)fx;
       const int y1 = y0 + (y0 < Hl - 1), x1 = x0 + (x0 < Wl - 1);
       const float ly1 = fy - y0, lx1 = fx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-      const bf16_t* lb = lo + (size_t)b * Hl * Wl * ld_lo + 8 * q;
-      const bf16_t* p00 = lb + ((size_t)y0 * Wl + x0) * ld_lo;
-      const bf16_t* p01 = lb + ((size_t)y0 * Wl + x1) * ld_lo;
-      const bf16_t* p10 = lb + ((size_t)y1 * Wl + x0) * ld_lo;
-      const bf16_t* p11 = lb + ((size_t)y1 * Wl + x1) * ld_lo;
+      const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
+      const unsigned o00 = ok ? (unsigned)(((y0 * Wl + x0) * ld_lo + 8 * q) * 2) : kOob, o01 = ok ? (unsigned)(((y0 * Wl + x1) * ld_lo + 8 * q) * 2) : kOob;
+      const unsigned o10 = ok ? (unsigned)(((y1 * Wl + x0) * ld_lo + 8 * q) * 2) : kOob, o11 = ok ? (unsigned)(((y1 * Wl + x1) * ld_lo + 8 * q) * 2) : kOob;
+      auto ldb = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off) {
+        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+      };
+      auto widen = [](bf16x8 v, f32x4& lo4, f32x4& hi4) {
+        lo4 = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        hi4 = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+      };
 #pragma unroll
       for (int g = 0; g < GB::KG; ++g) {
-        bf16x8 v = zero8;
-        if (ok) {
-          if (32 * g < c_lo) {
-            const bf16x8 v00 = *reinterpret_cast<const bf16x8*>(p00 + 32 * g);
-            const bf16x8 v01 = *reinterpret_cast<const bf16x8*>(p01 + 32 * g);
-            const bf16x8 v10 = *reinterpret_cast<const bf16x8*>(p10 + 32 * g);
-            const bf16x8 v11 = *reinterpret_cast<const bf16x8*>(p11 + 32 * g);
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-              v[e] = (bf16_t)(ly0 * (lx0 * (float)v00[e] + lx1 * (float)v01[e]) +
-                              ly1 * (lx0 * (float)v10[e] + lx1 * (float)v11[e]));
-          } else {
-            v = *reinterpret_cast<const bf16x8*>(src + 32 * g);
-          }
+        if (32 * g < c_lo) {   // (c_lo is workgroup-uniform: a scalar branch)
+          f32x4 al, ah, bl, bh, cl, ch, dl, dh;
+          widen(ldb(rs_lo, o00 + 64u * g), al, ah);
+          widen(ldb(rs_lo, o01 + 64u * g), bl, bh);
+          widen(ldb(rs_lo, o10 + 64u * g), cl, ch);
+          widen(ldb(rs_lo, o11 + 64u * g), dl, dh);
+          const f32x4 rl = w00 * al + w01 * bl + w10 * cl + w11 * dl, rh = w00 * ah + w01 * bh + w10 * ch + w11 * dh;
+          const bf16x4 pl = __builtin_convertvector(rl, bf16x4), ph = __builtin_convertvector(rh, bf16x4);
+          fa[i][g] = bf16x8{pl[0], pl[1], pl[2], pl[3], ph[0], ph[1], ph[2], ph[3]};
+        } else {
+          fa[i][g] = ldb(rs_in, aoff + 64u * g);
         }
-        fa[i][g] = v;
       }
     } else {
 #pragma unroll
-      for (int g = 0; g < GB::KG; ++g) fa[i][g] = ok ? *reinterpret_cast<const bf16x8*>(src + 32 * g) : zero8;
+      for (int g = 0; g < GB::KG; ++g)
+        fa[i][g] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(aoff + 64u * g), 0, 0));
     }
   }
   wstore(0);
