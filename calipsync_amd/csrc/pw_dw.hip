@@ -106,6 +106,8 @@ __device__ __forceinline__ void ups_tile_load(float* sG, const float* g, int ld,
                                      (void __attribute__((address_space(3)))*)(reinterpret_cast<char*>(sG) + (j * 4 + wave) * 1024), 16, 0, 0);
   }
 }
+// (four corner weights per pixel and fused multiply-adds, as P1 of the fused block does for its G slice: 8 instead of the
+// 18 packed operations of ATen's three-lerp form per four channels -- round 5; same value to fp32 rounding)
 template <int HW>
 __device__ __forceinline__ f32x4 ups_at_lds(const float* sG, int gy0, int y, int x, int cq) {
   constexpr int HL = HW / 2;
@@ -114,7 +116,8 @@ __device__ __forceinline__ f32x4 ups_at_lds(const float* sG, int gy0, int y, int
     const int p = (gy - gy0) * HL + gx;
     return *reinterpret_cast<const f32x4*>(sG + p * 32 + 4 * (cq ^ (p & 7)));
   };
-  return ups_lerp(ty, tx, at(ty.i0, tx.i0), at(ty.i0, tx.i1), at(ty.i1, tx.i0), at(ty.i1, tx.i1));
+  return (ty.l0 * tx.l0) * at(ty.i0, tx.i0) + (ty.l0 * tx.l1) * at(ty.i0, tx.i1) + (ty.l1 * tx.l0) * at(ty.i1, tx.i0) +
+         (ty.l1 * tx.l1) * at(ty.i1, tx.i1);
 }
 
 // The GEMM part both kernels share: acc[i] (i-th pixel tile of this wave) = W1 tile x A rows over the whole K, k-tiles
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(256, (FTGeom<HW, F, BN, KF, S, NST>::occ)) void pw_
     const int cs = lcol ^ ft_key<KF>(r);                   // swizzled source column
     if ((j * 4 + wave) * RPI < G::M_PAD) {
       const int row = m0 + (r < m_valid ? r : m_valid - 1);   // pad rows re-read the last pixel; never used
-      voff[j] = (int)((long long)row * lda * 4) + cs * 16;
+      voff[j] = (int)__umul24((unsigned)row, (unsigned)(lda * 4)) + cs * 16;   // rows < 2^24, row bytes < 2^24, operand < 2 GiB (launcher)
     } else {
       const int wr = r - G::M_PAD < BN ? r - G::M_PAD : 0;    // rows behind the tile (LPT rounds up) re-read W row 0
       voff[j] = (n0 + wr) * K * 4 + cs * 16;
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(256, (FSGeom<HW, SR, STRIDE, BN, KF>::occ)) void pw
     if ((j * 4 + wave) * RPI < G::M_PAD) {
       int row = row_base + r;                                // rows outside the frame / pad rows: any row of the frame
       row = row < row_lo ? row_lo : (row > row_lo + G::P - 1 ? row_lo + G::P - 1 : row);
-      voff[j] = (int)((long long)row * lda * 4) + cs * 16;
+      voff[j] = (int)__umul24((unsigned)row, (unsigned)(lda * 4)) + cs * 16;   // rows < 2^24, row bytes < 2^24, operand < 2 GiB (launcher)
     } else {
       const int wr = r - G::M_PAD < BN ? r - G::M_PAD : 0;
       voff[j] = (n0 + wr) * K * 4 + cs * 16;
