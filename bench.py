@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: f32-input MFMA == f32 vector peak (155.4 measured here,
                             # profiles/r2_mfma_clock.txt)
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
-PROFILE_TAG = "r4"          # profiles/<tag>_pmc_traffic.json, <tag>_mfma_busy.json, <tag>_*_kernel_stats_replay.csv feed
+PROFILE_TAG = "r5"          # profiles/<tag>_pmc_traffic.json, <tag>_mfma_busy.json, <tag>_*_kernel_stats_replay.csv feed
                             # roofline.traffic / mfma_busy / avg_kernel_us_rocprof -- only when their source_hash matches
 
 

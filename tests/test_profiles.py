@@ -116,6 +116,38 @@ def test_round4_profiles_reproduce_the_line(bench, traffic, busy, stats):
     assert abs(frac - roof["frac"]) / roof["frac"] < 0.10, (frac, roof["frac"])
 
 
+R5 = [("r5_bench.json", "r5_pmc_traffic.json", "r5_mfma_busy.json", "r5_f32_b64_kernel_stats_replay"),
+      ("r5_bench_bf16_b512.json", "r5_pmc_traffic_bf16_b512.json", "r5_mfma_busy_bf16_b512.json",
+       "r5_bf16_b512_kernel_stats_replay")]
+
+
+@pytest.mark.parametrize("bench,traffic,busy,stats", R5)
+def test_round5_profiles_reproduce_the_line(bench, traffic, busy, stats):
+    """Round 5: the same contract as round 4 -- ONE collection (`tools/collect_profiles.sh r5 f32|bf16`), one source hash
+    over the set, replay-only statistics, HIP events within 10 % of rocprofv3, MFMA-busy normalised by the trace pass."""
+    test_round4_profiles_reproduce_the_line(bench, traffic, busy, stats)
+
+
+def test_round5_line_carries_the_single_gpu_anchor_of_configs3():
+    """the N = 1 line carries the 512-frame fp32 shard of BASELINE configs[3] with its own whole-net
+    fractions and the whole 4096-frame job walked through one GPU in 512-frame chunks (the point an N > 1
+    `config.strong_scaling` is divided by), next to the blocks round 3 introduced."""
+    path = os.path.join(PROF, "r5_bench.json")
+    if not os.path.exists(path):
+        pytest.skip("profiles/r5_bench.json not collected yet")
+    line = json.load(open(path))
+    assert line["dtype"] == "f32" and "batch=64" in line["config"]["workload"] and line["n_gpus"] == 1
+    sec = line["secondary"]
+    assert set(sec) >= {"b8_fp32", "e2e", "bf16_b512", "fp32_b512", "strong_n1"}
+    f512, strong = sec["fp32_b512"], sec["strong_n1"]
+    assert f512["batch"] == 512 and f512["dtype"] == "f32" and 0 < f512["whole_net"]["mfma_frac_executed"] <= f512["whole_net"]["mfma_frac"] < 1
+    assert strong["global_batch"] == 4096 and strong["frames_per_gpu"] == 4096 and strong["chunk"] == 512 and strong["chunks_per_step"] == 8
+    assert strong["scaling"] == "strong" and strong["n_gpus"] == 1
+    # eight 512-frame chunks through one arena cost what eight 512-frame forwards cost (no per-chunk penalty): within 5 %
+    assert abs(strong["value"] - f512["value"]) / f512["value"] < 0.05
+    assert "NOT the parity path" in sec["bf16_b512"]["dtype"] and sec["bf16_b512"]["value"] > sec["fp32_b512"]["value"]
+
+
 def test_round3_line_carries_the_secondary_block():
     """the driver's plain `bench.py` run also reports configs[2], the frame loop and the reference's own
     B=8 shape -- next to the headline, never instead of it."""

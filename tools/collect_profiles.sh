@@ -10,7 +10,7 @@
 # counters only when the hash matches the sources of the library it runs.  Results land in gpurun_out/profiles_<tag>/
 # (copy them into profiles/ and commit).
 set -e
-tag=${1:-r4}
+tag=${1:-r5}
 dt=${2:-f32}
 R=$GRAFT_REPO_ROOT
 extra=""; sfx=""; cfg="f32_b64"; what="B=64 fp32"
