@@ -298,6 +298,24 @@ def test_bf16_intermediates_track_fp32(net_bf16, golden, name):
     assert rel < BF16_TAP_BARS[name]
 
 
+@pytest.mark.parametrize("batch", [11, 12, 31, 40])
+def test_bf16_plan_switch_batches_against_oracle(net_bf16, recipe_sd, batch):
+    """The bf16 engine either side of its plan switches: 11 frames (GEMM + depthwise launches, materialised upsample), 12 and
+    31 (single lane: expand + depthwise in one kernel, commuted upsample of up1.0 / up2.0, attention on bf16 matrix
+    instructions), 40 (two lanes of 20).  First, middle and last frame against the CPU oracle under the bf16 error bars of
+    the golden test."""
+    from oracle import unet_oracle
+    x, a = recipe.make_inputs_range(500, batch)
+    out = net_bf16(torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda())
+    assert out.shape == (batch, 3, 160, 160) and torch.isfinite(out).all()
+    pick = [0, batch // 2, batch - 1]
+    torch.set_num_threads(16)
+    ref = unet_oracle.forward(unet_oracle.to_torch(recipe_sd), torch.from_numpy(x[pick]), torch.from_numpy(a[pick]))
+    d = (out[pick].cpu() - ref).abs()
+    print(f"bf16 B={batch} vs oracle: max {float(d.max()):.3e} mean {float(d.mean()):.3e}")
+    assert float(d.max()) < 1.1e-2 and float(d.mean()) < 1.3e-3, (float(d.max()), float(d.mean()))
+
+
 def test_bf16_frames_independent(net_bf16):
     x, a = recipe.make_inputs(5)
     xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
