@@ -136,3 +136,17 @@ def test_header_is_c99_and_a_plain_c_host_can_bind_it(lib, tmp_path):
     out = subprocess.run([str(exe), _lib.lib_path()], check=True, capture_output=True, text=True).stdout
     items, total = _lib.packed_layout()
     assert f"abi {_lib.ABI_VERSION} tensors {len(items)} " in out and f"total {total} " in out and "gammas 4" in out
+
+
+def test_every_engine_option_is_documented():
+    """Every switch `casync_set_option` knows (the name table of csrc/runtime.hip) appears in DESIGN.md's option table, and the
+    library answers for each of them (no GPU needed: the process defaults)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = re.findall(r'\{"([a-z0-9_]+)", &CasyncOptions::', open(os.path.join(root, "calipsync_amd", "csrc", "runtime.hip")).read())
+    assert len(names) >= 30
+    design = open(os.path.join(root, "DESIGN.md")).read()
+    missing = [n for n in names if f"`{n}`" not in design]
+    assert not missing, f"options missing from DESIGN.md section 4: {missing}"
+    for n in names:
+        assert isinstance(_lib.get_option(n), int)
