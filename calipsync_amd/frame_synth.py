@@ -250,7 +250,7 @@ class VideoStreamManager:
     pre-extracted windows; no HuBERT weights ship), so ``hubert_path`` may be a callable
     ``audio_path -> [T,2,1024] array`` or is ignored when ``audio_path`` is itself a ``.npy`` of
     features.  The mp4 writer / ffmpeg mux (inference.py:88-110) is used when cv2 / ffmpeg exist; otherwise
-    the frames go to ``<output_path>.npy``."""
+    the frames are written as a Motion-JPEG ``.avi`` with Pillow (``mjpeg_avi.py``; no audio track)."""
 
     def __init__(self, data_dir: str, unet_checkpoint: Optional[str], hubert_path=None, device: str = "cuda:0",
                  batch_size: int = 8, output_sample_rate: int = 24000, **synth_kwargs):
@@ -274,8 +274,16 @@ class VideoStreamManager:
         try:
             import cv2
         except ImportError:
-            np.save(output_path + ".npy", np.stack(frames))
-            return output_path + ".npy"
+            # no OpenCV in this environment: a Motion-JPEG AVI written with Pillow (calipsync_amd/mjpeg_avi.py; no audio
+            # track -- muxing needs the ffmpeg binary), or the raw frames when Pillow is missing too
+            try:
+                from . import mjpeg_avi
+                out = os.path.splitext(output_path)[0] + ".avi"
+                mjpeg_avi.write_mjpeg_avi(out, frames, fps=self.fps)
+                return out
+            except ImportError:
+                np.save(output_path + ".npy", np.stack(frames))
+                return output_path + ".npy"
         height, width = frames[0].shape[:2]
         temp = output_path.replace(".mp4", "_temp.mp4")
         writer = cv2.VideoWriter(temp, cv2.VideoWriter_fourcc(*"mp4v"), self.fps, (width, height))

@@ -1,0 +1,95 @@
+"""Motion-JPEG AVI writer without OpenCV / ffmpeg: the offline driver's fallback container.
+
+The reference saves its frames with ``cv2.VideoWriter(..., 'mp4v', fps, (w, h))`` and muxes the audio with the ``ffmpeg``
+binary (inference.py:88-110).  Neither exists in this image; ``VideoStreamManager`` uses them when they do.  Without them
+the frames used to go to a ``.npy`` file only; this module writes them as a playable video instead: every frame is
+JPEG-encoded with Pillow and stored as one ``00dc`` chunk of a RIFF/AVI file ('MJPG' stream, an ``idx1`` index, fixed
+frame rate).  No audio track (muxing needs an encoder this image does not have).  Host code only.
+"""
+from __future__ import annotations
+
+import io
+import struct
+from typing import Iterable, List
+
+import numpy as np
+
+
+def _chunk(fourcc: bytes, data: bytes) -> bytes:
+    return fourcc + struct.pack("<I", len(data)) + data + (b"\0" if len(data) & 1 else b"")
+
+
+def _list(kind: bytes, data: bytes) -> bytes:
+    return b"LIST" + struct.pack("<I", len(data) + 4) + kind + data
+
+
+def encode_jpeg(frame_bgr: np.ndarray, quality: int = 95) -> bytes:
+    """One BGR uint8 HxWx3 frame (the frame loop's layout, cv2 order) as a baseline JPEG."""
+    from PIL import Image
+    if frame_bgr.dtype != np.uint8 or frame_bgr.ndim != 3 or frame_bgr.shape[2] != 3:
+        raise ValueError(f"frames must be uint8 HxWx3 (BGR), got {frame_bgr.dtype} {frame_bgr.shape}")
+    buf = io.BytesIO()
+    # 4:4:4 (no chroma subsampling): the synthesised mouth region is small and colour edges matter more than file size
+    Image.fromarray(np.ascontiguousarray(frame_bgr[:, :, ::-1])).save(buf, format="JPEG", quality=quality, subsampling=0)
+    return buf.getvalue()
+
+
+def write_mjpeg_avi(path: str, frames: Iterable[np.ndarray], fps: float = 25.0, quality: int = 95) -> int:
+    """Write `frames` (BGR uint8, all the same size) to `path` as Motion-JPEG AVI; returns the frame count."""
+    jpegs: List[bytes] = []
+    width = height = None
+    for f in frames:
+        if width is None:
+            height, width = f.shape[:2]
+        elif f.shape[:2] != (height, width):
+            raise ValueError("all frames of a video must have the same size")
+        jpegs.append(encode_jpeg(f, quality))
+    if not jpegs:
+        raise ValueError("no video frame was generated")
+    n = len(jpegs)
+    biggest = max(len(j) for j in jpegs)
+    usec = int(round(1e6 / fps))
+    rate, scale = int(round(fps * 1000)), 1000
+    avih = struct.pack("<14I", usec, int(biggest * fps), 0, 0x10, n, 0, 1, biggest, width, height, 0, 0, 0, 0)   # 0x10 = AVIF_HASINDEX
+    strh = b"vids" + b"MJPG" + struct.pack("<IHHIIIIIIII4H", 0, 0, 0, 0, scale, rate, 0, n, biggest, 0xFFFFFFFF, 0, 0, 0, width, height)
+    strf = struct.pack("<IiiHH4sIiiII", 40, width, height, 1, 24, b"MJPG", width * height * 3, 0, 0, 0, 0)
+    hdrl = _list(b"hdrl", _chunk(b"avih", avih) + _list(b"strl", _chunk(b"strh", strh) + _chunk(b"strf", strf)))
+    movi_body, index, off = b"", b"", 4                      # idx1 offsets count from the 'movi' fourcc
+    parts = []
+    for j in jpegs:
+        parts.append(_chunk(b"00dc", j))
+        index += b"00dc" + struct.pack("<III", 0x10, off, len(j))   # 0x10 = AVIIF_KEYFRAME
+        off += len(parts[-1])
+    movi_body = b"".join(parts)
+    riff_body = b"AVI " + hdrl + _list(b"movi", movi_body) + _chunk(b"idx1", index)
+    with open(path, "wb") as fh:
+        fh.write(b"RIFF" + struct.pack("<I", len(riff_body)) + riff_body)
+    return n
+
+
+def read_mjpeg_avi(path: str):
+    """(fps, [BGR frames]) of a file written by `write_mjpeg_avi` (tests; a minimal RIFF walk, not a general AVI reader)."""
+    from PIL import Image
+    data = open(path, "rb").read()
+    if data[:4] != b"RIFF" or data[8:12] != b"AVI ":
+        raise ValueError("not a RIFF/AVI file")
+    fps, frames = None, []
+
+    def walk(lo: int, hi: int) -> None:
+        nonlocal fps
+        pos = lo
+        while pos + 8 <= hi:
+            cc, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+            body = pos + 8
+            if cc == b"LIST":
+                walk(body + 4, body + size)
+            elif cc == b"strh":
+                scale, rate = struct.unpack("<II", data[body + 20:body + 28])
+                fps = rate / scale
+            elif cc == b"00dc":
+                im = Image.open(io.BytesIO(data[body:body + size])).convert("RGB")
+                frames.append(np.ascontiguousarray(np.asarray(im)[:, :, ::-1]))
+            pos = body + size + (size & 1)
+
+    walk(12, len(data))
+    return fps, frames

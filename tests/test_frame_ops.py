@@ -4,6 +4,7 @@ frame-walk / iterator contract on the CPU; the device process_batch == oracle, b
 cv2 is absent from this image, so the oracle (oracle/frame_ops_oracle.py) is PARITY UNPINNED against
 the real library; what these tests pin is (a) properties any correct restatement must have and (b) that
 the HIP kernels compute exactly what the restatement computes."""
+import os
 import random
 
 import numpy as np
@@ -338,3 +339,33 @@ def test_frame_synthesizer_end_to_end(gpu_net, tmp_path):
             assert np.array_equal(out[k]["frame"], frame), (start, j)
             k += 1
     assert any(not np.array_equal(o["frame"], imgs[o["physical_index"]]) for o in out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_flight", [1, 0])
+def test_video_stream_manager_writes_a_playable_file(gpu_net, tmp_path, in_flight):
+    """The offline driver end to end (inference.py:47-110): features -> synthesised frames -> a video file.  Without cv2 /
+    ffmpeg (this image) the container is Motion-JPEG AVI written with Pillow; its frames are the iterator's frames (to JPEG
+    tolerance), in order, at the reference's 25 fps.  Both loop orders (one batch in flight / batch by batch) give the same
+    frames."""
+    from calipsync_amd import mjpeg_avi
+    from calipsync_amd.frame_synth import FrameSynthesizer, VideoStreamManager
+    data = tmp_path / "data"
+    write_dataset(str(data), 10, 270, 360, seed=4)
+    feats = np.random.default_rng(5).standard_normal((9, 2, 1024)).astype(np.float32)
+    np.save(str(tmp_path / "feats.npy"), feats)
+    vsm = VideoStreamManager(str(data), None, device="cuda:0", batch_size=4, seed=9, net=gpu_net, batches_in_flight=in_flight)
+    out = vsm.process_single_file(str(tmp_path / "feats.npy"), str(tmp_path / "out.mp4"))
+    try:
+        import cv2  # noqa: F401
+        assert out.endswith(".mp4") and os.path.getsize(out) > 0
+        return
+    except ImportError:
+        pass
+    assert out.endswith(".avi")
+    fps, frames = mjpeg_avi.read_mjpeg_avi(out)
+    want = [o["frame"] for o in FrameSynthesizer(None, str(data), device="cuda:0", batch_size=4, seed=9, net=gpu_net)
+            .iterate_synthesized_frames(feats, 0, True)]
+    assert fps == 25.0 and len(frames) == len(want) == 9
+    for a, b in zip(want, frames):
+        assert a.shape == b.shape and np.abs(a.astype(int) - b.astype(int)).mean() < 12.0     # random-noise frames: JPEG is lossy
