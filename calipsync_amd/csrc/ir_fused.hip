@@ -199,7 +199,20 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the same number in a scalar register (LDS-DMA destinations)
   const int l15 = lane & 15, q = lane >> 4;
-  const int b = blockIdx.z, oy0 = blockIdx.y * G::TH, ox0 = blockIdx.x * TW;
+  // XCD-aware tile order (round 5): workgroups t, t + 8, ... share an XCD and its L2; each XCD gets a contiguous run of the
+  // launch's tiles, i.e. whole frames, so the halo rows / columns (and the G tiles of the commuted upsample) that neighbouring
+  // tiles share are fetched from HBM once instead of once per XCD (up4.0 moved 495 MB per launch for 315 MB algorithmic,
+  // profiles/r5_pmc_traffic.json; not a bound in fp32 -- measured neutral in time -- but it is traffic the chip need not move)
+  int b, oy0, ox0;
+  {
+    const int nwg = gridDim.x, t = blockIdx.x, qn = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
+    const int bid = (xcd < r ? xcd * (qn + 1) : r * (qn + 1) + (xcd - r) * qn) + idx;
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + G::TH - 1) / G::TH, per_frame = tiles_x * tiles_y;
+    b = bid / per_frame;
+    const int rem = bid - b * per_frame, ty = rem / tiles_x;
+    oy0 = ty * G::TH;
+    ox0 = (rem - ty * tiles_x) * TW;
+  }
   const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
   const T* inb = in + (size_t)b * H * W * ld_in;
   // does the halo leave the image?  (workgroup-uniform)
@@ -663,54 +676,71 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, q = lane >> 4;
-  const int b = blockIdx.z, oy0 = blockIdx.y * G::TH, ox0 = blockIdx.x * TW;
+  // XCD-aware tile order (round 5): workgroups t, t + 8, ... share an XCD and its L2; each XCD gets a contiguous run of the
+  // launch's tiles, i.e. whole frames -- the halo rows / columns neighbouring tiles share (and the low-resolution taps of the Up
+  // blocks) are fetched from HBM once instead of once per XCD (down1.0 moved 1,173 MB per 256-frame launch at 5.4 TB/s for
+  // 630 MB of input + output; up4.0 fetched 2.6 x its input: profiles/r5_pmc_traffic_bf16_b512.json)
+  int b, oy0, ox0;
+  {
+    const int nwg = gridDim.x, t = blockIdx.x, qn = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
+    const int bid = (xcd < r ? xcd * (qn + 1) : r * (qn + 1) + (xcd - r) * qn) + idx;
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + G::TH - 1) / G::TH, per_frame = tiles_x * tiles_y;
+    b = bid / per_frame;
+    const int rem = bid - b * per_frame, ty = rem / tiles_x;
+    oy0 = ty * G::TH;
+    ox0 = (rem - ty * tiles_x) * TW;
+  }
   const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
   const bf16_t* inb = in + (size_t)b * H * W * ld_in;
   const bool border = iy0 < 0 || ix0 < 0 || iy0 + G::IH > H || ix0 + G::IW > W;
 
-  // ---- weight chunk: global -> registers -> the other half of the LDS weight area ----
-  f32x4 rw1[GB::NW1], rw2[GB::NW2], rwd;
-  auto wload = [&](int ce0) {
+  // ---- weight chunks: HBM / L2 -> LDS by LDS-DMA (global_load_lds, 16 B per lane, a wave's 64 pieces land contiguously),
+  //      as in the fp32 kernel: no staging registers, no ds_write, and -- what matters in a kernel bound by vector-instruction
+  //      issue -- no per-chunk address arithmetic (round 4 staged through registers and recomputed the swizzled LDS address of
+  //      every piece in every chunk: 93 of 363 vector instructions per chunk and wave).  The LDS images are swizzled (xsb()),
+  //      so the permutation is applied on the SOURCE side: LDS column s of row r receives global column s ^ key(r) (the XOR
+  //      is its own inverse within a row).  Two groups with different lead: A = W1c + b1 of chunk c (read by P1(c), i.e.
+  //      BEFORE the chunk's first barrier) and B = W2c + taps + bd of chunk c (read by P2 / P3 (c)); both are requested a
+  //      whole chunk ahead of their first use and waited for at the chunk's first barrier only. ----
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  unsigned src1[GB::NW1], src2[GB::NW2];   // byte offsets of this thread's pieces from the chunk's W1 block / from w2 + chunk column
 #pragma unroll
-    for (int j = 0; j < GB::NW1; ++j) {
-      const int idx = tid + 256 * j;   // 16-B piece of the contiguous [32][CIN] bf16 chunk
-      if (idx < 4 * CIN) rw1[j] = *reinterpret_cast<const f32x4*>(w1 + (size_t)ce0 * CIN + idx * 8);
-    }
+  for (int j = 0; j < GB::NW1; ++j) {
+    const int idx = tid + 256 * j, r = idx / (CIN / 8), pc = idx - r * (CIN / 8);   // LDS row, physical 16-B column
+    src1[j] = (unsigned)(xsb<CIN * 2>(r, pc * 16));                                  // = byte offset of logical column pc ^ key(r) of row r
+  }
 #pragma unroll
-    for (int j = 0; j < GB::NW2; ++j) {
-      const int idx = tid + 256 * j;   // row = idx/4, 16-B piece idx%4 of the 64-B row slice
-      if (idx < COUT * 4) rw2[j] = *reinterpret_cast<const f32x4*>(w2 + (size_t)(idx >> 2) * CE + ce0 + (idx & 3) * 8);
-    }
-    if (tid < 88) {                    // 11 rows (9 taps, b1, bd) x 32 floats = 88 float4
-      const int t = tid >> 3, c4 = (tid & 7) * 4;
-      const float* src = t < 9 ? wd + (size_t)t * CE : (t == 9 ? b1 : bd);
-      rwd = *reinterpret_cast<const f32x4*>(src + ce0 + c4);
-    }
+  for (int j = 0; j < GB::NW2; ++j) {
+    const int idx = tid + 256 * j, r = idx >> 2, pc = idx & 3;
+    src2[j] = (unsigned)(r * CE * 2 + (xsb<64>(r, pc * 16) - r * 64));
+  }
+  const int tap_row = tid >> 3, tap_c4 = (tid & 7) * 4;      // taps block: 11 rows (9 taps, b1, bd) x 32 floats = 88 pieces
+  const float* tap_src = (tap_row < 9 ? wd + (size_t)tap_row * CE : (tap_row == 9 ? b1 : bd)) + tap_c4;
+  auto dma16 = [&](const void* sbase, unsigned off, char* dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(static_cast<const char*>(sbase) + off),
+                                     (void __attribute__((address_space(3)))*)dst_wave_base, 16, 0, 0);
   };
-  auto wstore = [&](int buf) {
+  auto stage_a = [&](int c, int buf) {   // W1c [32][CIN] + b1 of chunk c -> buffer buf
     char* wb = sW + buf * GB::WBUF;
 #pragma unroll
-    for (int j = 0; j < GB::NW1; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < 4 * CIN) {
-        const int r = idx / (CIN / 8), cb = (idx - r * (CIN / 8)) * 16;
-        *reinterpret_cast<f32x4*>(wb + GB::wW1 + xsb<CIN * 2>(r, cb)) = rw1[j];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < GB::NW2; ++j) {
-      const int idx = tid + 256 * j;
-      if (idx < COUT * 4) *reinterpret_cast<f32x4*>(wb + GB::wW2 + xsb<64>(idx >> 2, (idx & 3) * 16)) = rw2[j];
-    }
-    if (tid < 88) *reinterpret_cast<f32x4*>(wb + GB::wWd + tid * 16) = rwd;
+    for (int j = 0; j < GB::NW1; ++j)
+      if (tid + 256 * j < 4 * CIN) dma16(w1 + (size_t)c * CC * CIN, src1[j], wb + GB::wW1 + (256 * j + 64 * wave_s) * 16);
+    if (tap_row == 9) dma16(tap_src + c * CC, 0u, wb + GB::wWd + 64 * wave_s * 16);
   };
-
-  wload(0);
+  auto stage_b = [&](int c, int buf) {   // W2c [COUT][32] + taps + bd of chunk c -> buffer buf
+    char* wb = sW + buf * GB::WBUF;
+#pragma unroll
+    for (int j = 0; j < GB::NW2; ++j)
+      if (tid + 256 * j < COUT * 4) dma16(w2 + c * CC, src2[j], wb + GB::wW2 + (256 * j + 64 * wave_s) * 16);
+    if (tid < 88 && tap_row != 9) dma16(tap_src + c * CC, 0u, wb + GB::wWd + 64 * wave_s * 16);
+  };
+  stage_a(0, 0);
+  if (NCH > 1) stage_a(1, 1);
+  stage_b(0, 0);
   // ---- A fragments of this wave's halo rows: HBM -> registers, once.  Round 5: the tile index is a scalar (wave_s), every
   //      access is a buffer access with a 32-bit lane offset (a pixel outside the image = an offset past the end = zeros), and
   //      the on-the-fly bilinear x2 of the Up blocks is a weighted sum of its four corners with packed fused multiply-adds
   //      (corner weights once per pixel) -- the prologue was 848 of ~2,000 vector instructions per wave in up4.0 ----
-  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   constexpr unsigned kOob = 0x80000000u;
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(inb), 0, (unsigned)H * W * ld_in * 2u, 0x00020000);
   bf16x8 fa[G::MT1][GB::KG];
@@ -761,8 +791,7 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
         fa[i][g] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)(aoff + 64u * g), 0, 0));
     }
   }
-  wstore(0);
-  if (NCH > 1) wload(CC);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces (chunks 0 / 1) have landed
   __syncthreads();
 
   f32x4 acc3[G::MT3][G::NT3];
@@ -821,11 +850,12 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
         }
       }
     }
-    __syncthreads();  // E complete; every wave is done with the previous chunk's P3
-    if (ch + 1 < NCH) {
-      wstore((ch + 1) & 1);
-      if (ch + 2 < NCH) wload((ch + 2) * CC);
-    }
+    // E complete; every wave is done with the previous chunk's P3; what was requested a chunk ago (W1c / b1 of chunk ch + 1,
+    // W2c / taps / bd of chunk ch) has landed and is visible
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ch + 2 < NCH) stage_a(ch + 2, ch & 1);        // P1(ch) was the last reader of that W1 / b1 slot
+    if (ch + 1 < NCH) stage_b(ch + 1, (ch + 1) & 1);  // P3(ch - 1) was the last reader of that W2 / taps slot
 
     // ---- P2: depthwise 3x3 over E; thread = 8 channels (16-B column q of a pixel) x NPX pixels STACKED IN Y of column
     //      l15, rows MT3 * wave + j -- exactly what P3's MFMA wants from this lane as its B operand (k = 8 q + j), so D
@@ -869,7 +899,11 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
         fd[j] = bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
       }
     }
-    __syncthreads();  // every wave is done reading E (the next P1 overwrites it); the parked weights are visible
+    // every wave is done reading E (the next P1 overwrites it).  A raw barrier: the requests just issued must NOT be waited
+    // for here (__syncthreads would: s_waitcnt vmcnt(0)); P2 wrote nothing to LDS and its reads are consumed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 
     // ---- P3: project GEMM, one 32-deep MFMA per output tile and chunk (W2c = A operand,
     //      pixels = B operand: acc3[i][n] holds channels 16n+4q..+3 of pixel 16(wave*MT3+i)+l15) ----
@@ -928,7 +962,7 @@ int launch_inst_b(const bf16_t* lo, int ld_lo, int c_lo, const bf16_t* in, int l
   static unsigned long long attr_once = 0;
   if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)lds)) return st;
   const int ho = (h + 2 - 3) / STRIDE + 1, wo = (w + 2 - 3) / STRIDE + 1;
-  dim3 grid((wo + TW - 1) / TW, (ho + G::TH - 1) / G::TH, batch);
+  dim3 grid((unsigned)(((wo + TW - 1) / TW) * ((ho + G::TH - 1) / G::TH) * batch));   // one dimension: the kernel orders the tiles by XCD
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2, b2,
                      out, ld_out, h, w, ho, wo, res);
   CASYNC_CHECK_HIP(hipGetLastError());
@@ -945,7 +979,7 @@ int launch_inst_t(const T* lo, int ld_lo, int c_lo, const T* in, int ld_in, cons
   static unsigned long long attr_once = 0;
   if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)lds)) return st;
   const int ho = (h + 2 - 3) / STRIDE + 1, wo = (w + 2 - 3) / STRIDE + 1;
-  dim3 grid((wo + TW - 1) / TW, (ho + G::TH - 1) / G::TH, batch);
+  dim3 grid((unsigned)(((wo + TW - 1) / TW) * ((ho + G::TH - 1) / G::TH) * batch));   // one dimension: the kernel orders the tiles by XCD
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, lo, ld_lo, c_lo, in, ld_in, w1, b1, wd, bd, w2,
                      b2, out, ld_out, h, w, ho, wo, res, g_ir_stamps);
   CASYNC_CHECK_HIP(hipGetLastError());
