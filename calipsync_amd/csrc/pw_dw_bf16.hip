@@ -87,12 +87,12 @@ __device__ __forceinline__ void pw_dw_gemm_b(char* ring, const bf16_t* __restric
 #pragma unroll
   for (int i = 0; i < G::MTW; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // Two k-tiles in flight on a two-stage ring.  With matrix instructions 8 x faster than fp32 a k-tile's MFMAs (~400 cycles)
-  // are far shorter than the latency of its LDS-DMA fill, so the fp32 kernel's schedule -- k-tile kt + 1 requested at the
-  // top of iteration kt -- leaves the loop waiting on one fill per iteration (measured: 1,600-1,750 cycles per k-tile and CU
-  // on up2.0 / up1.0 for ~700 of LDS time).  Here every fragment of k-tile kt is read into registers first; a second barrier
-  // says "everyone has read stage kt & 1", the fill of k-tile kt + 2 goes into that stage at once, and the MFMAs of k-tile
-  // kt run under it: a fill has two iterations to arrive.
+  // Two k-tiles in flight on a two-stage ring: every fragment of k-tile kt is read into registers first, a second barrier
+  // says "everyone has read stage kt & 1", the fill of k-tile kt + 2 goes into that stage at once and the MFMAs of k-tile kt
+  // run under it, so a fill has two iterations to arrive.  Measured against the fp32 kernel's schedule (k-tile kt + 1 requested
+  // at the top of iteration kt): no difference end to end (profiles/r5_ab_bf16_pw_dw.txt) -- with matrix instructions 8 x
+  // faster than fp32 the loop is bound by the BYTES its fills move through LDS (hence the 64- / 128-channel tiles), not by
+  // their latency.  Kept: it costs nothing and is the safer schedule at low occupancy.
   issue(0, 0);
   if (nk > 1) issue(1, 1);
   for (int kt = 0; kt < nk; ++kt) {
