@@ -649,7 +649,6 @@ struct IRGeomB {
   static constexpr int EBYTES = G::IH * (G::IW * 64 + 16);
   static constexpr int oE = 0, oW = (oE + EBYTES + 15) / 16 * 16;
   static constexpr int total = oW + 2 * WBUF;
-  static_assert(G::OP * G::LDO * 4 <= total, "epilogue staging must fit in E+D+W");
   static_assert(WBUF % 16 == 0, "16-B aligned carve");
   static constexpr int NW1 = (32 * CIN * 2 / 16 + 255) / 256;   // 16-B pieces per thread
   static constexpr int NW2 = (COUT * 64 / 16 + 255) / 256;
@@ -905,48 +904,48 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    // ---- P3: project GEMM, one 32-deep MFMA per output tile and chunk (W2c = A operand,
-    //      pixels = B operand: acc3[i][n] holds channels 16n+4q..+3 of pixel 16(wave*MT3+i)+l15) ----
+    // ---- P3: project GEMM, one 32-deep MFMA per output tile and chunk (W2c = A operand, pixels = B operand).  The rows of
+    //      W2c enter the MFMA permuted -- A row r of tile n = 2m + h is output channel 32m + 8(r >> 2) + 4h + (r & 3) -- so that
+    //      a lane's accumulator rows 4q .. 4q+3 of tiles 2m and 2m+1 are the EIGHT CONSECUTIVE channels 32m + 8q .. + 7 of pixel
+    //      16(wave*MT3+i)+l15: one 16-byte store per pixel and pair of tiles, straight from the accumulators (epilogue below).
+    //      (Reads stay conflict free: the four row groups a 16-lane read group touches still sit on four different keys.) ----
     {
       bf16x8 fb[G::NT3];
 #pragma unroll
       for (int n = 0; n < G::NT3; ++n)
-        fb[n] = *reinterpret_cast<const bf16x8*>(wb + GB::wW2 + xsb<64>(16 * n + l15, 16 * q));
+        fb[n] = *reinterpret_cast<const bf16x8*>(wb + GB::wW2 + xsb<64>(32 * (n >> 1) + 8 * (l15 >> 2) + 4 * (n & 1) + (l15 & 3), 16 * q));
 #pragma unroll
       for (int i = 0; i < G::MT3; ++i)
 #pragma unroll
         for (int n = 0; n < G::NT3; ++n) acc3[i][n] = mfma16b(fb[n], fd[i], acc3[i][n]);
     }
   }
-  __syncthreads();
 
-  // ---- epilogue: + b2, LReLU -> fp32 LDS staging (32 columns at a time, one float4 per lane and
-  //      tile) -> coalesced bf16 rows ----
-  float* sO = reinterpret_cast<float*>(smem_b);
+  // ---- epilogue: + b2, LReLU (+ the block input), eight channels per lane -> one 16-byte buffer store per pixel and pair of
+  //      channel tiles, straight from the accumulators: no LDS staging, no barrier, one 32-bit offset per pixel (a pixel past
+  //      the image edge = an offset past the end of the frame: the store is dropped).  Round 4 staged 32 fp32 columns at a time
+  //      through LDS and stored 8 bytes per lane with a 64-bit address each: the stores were 0.8 of the 12 ms bf16 step ----
+  static_assert(G::NT3 % 2 == 0, "channel tiles are stored in pairs");
   bf16_t* outb = out + (size_t)b * Ho * Wo * ld_out;
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(outb, 0, (unsigned)Ho * Wo * ld_out * 2u, 0x00020000);
 #pragma unroll
-  for (int n0 = 0; n0 < G::NT3; n0 += 2) {
-    if (n0) __syncthreads();
+  for (int m = 0; m < G::NT3 / 2; ++m) {
+    const f32x4 bias0 = *reinterpret_cast<const f32x4*>(b2 + 32 * m + 8 * q), bias1 = *reinterpret_cast<const f32x4*>(b2 + 32 * m + 8 * q + 4);
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn) {
-      const f32x4 bias = *reinterpret_cast<const f32x4*>(b2 + 16 * (n0 + nn) + 4 * q);
-#pragma unroll
-      for (int i = 0; i < G::MT3; ++i) {
-        const int p = 16 * (wave * G::MT3 + i) + l15;
-        *reinterpret_cast<f32x4*>(sO + p * G::LDO + 16 * nn + 4 * q) = lrelu4(acc3[i][n0 + nn] + bias);
+    for (int i = 0; i < G::MT3; ++i) {
+      const int oy = oy0 + wave_s * G::MT3 + i, ox = ox0 + l15;   // tile i of this wave = output row wave*MT3 + i (TW = 16)
+      const bool ok = oy < Ho && ox < Wo;
+      f32x4 v0 = lrelu4(acc3[i][2 * m] + bias0), v1 = lrelu4(acc3[i][2 * m + 1] + bias1);
+      if (res) {   // stride 1, CIN == COUT: + the block input pixel
+        const unsigned roff = ok ? (unsigned)(((oy * W + ox) * ld_in + 32 * m + 8 * q) * 2) : kOob;
+        const bf16x8 x = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)roff, 0, 0));
+        v0 += f32x4{(float)x[0], (float)x[1], (float)x[2], (float)x[3]};
+        v1 += f32x4{(float)x[4], (float)x[5], (float)x[6], (float)x[7]};
       }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < G::OP * 8; idx += 256) {
-      const int p = idx >> 3, c4 = (idx & 7) * 4;
-      const int py = p / TW, px = p - py * TW;
-      const int oy = oy0 + py, ox = ox0 + px;
-      if (oy < Ho && ox < Wo) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(sO + p * G::LDO + c4);
-        const int c = 16 * n0 + c4;
-        if (res) v += ld4(inb + ((size_t)oy * W + ox) * ld_in + c);
-        st4(outb + ((size_t)oy * Wo + ox) * ld_out + c, v);
-      }
+      const bf16x4 h0 = __builtin_convertvector(v0, bf16x4), h1 = __builtin_convertvector(v1, bf16x4);
+      const bf16x8 o = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      const unsigned ooff = ok ? (unsigned)(((oy * Wo + ox) * ld_out + 32 * m + 8 * q) * 2) : kOob;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)ooff, 0, 0);
     }
   }
 }
