@@ -20,13 +20,16 @@ lib.casync_op_set_dtype(1 if bf16 else 0)
 tdt = torch.bfloat16 if bf16 else torch.float32
 s = torch.cuda.current_stream().cuda_stream
 for m, n, k in shapes:
-    a = torch.randn(m, k, device=dev).to(tdt)
+    pad = int(os.environ.get("LDA_PAD", "0"))      # extra elements per A row (leading dimension k + pad)
+    cpad = int(os.environ.get("LDC_PAD", "0"))
+    abuf = torch.randn(m, k + pad, device=dev).to(tdt)
+    a = abuf
     w = (torch.randn(n, k, device=dev) / k ** 0.5).to(tdt)
     bias = torch.randn(n, device=dev)
-    c = torch.empty(m, n, device=dev, dtype=tdt)
+    c = torch.empty(m, n + cpad, device=dev, dtype=tdt)
 
     def run():
-        st = lib.casync_op_pw_gemm(a.data_ptr(), k, w.data_ptr(), bias.data_ptr(), c.data_ptr(), n, m, n, k, 1, 0, 0, 0, 0, 0, 0, 0, s)
+        st = lib.casync_op_pw_gemm(a.data_ptr(), k + pad, w.data_ptr(), bias.data_ptr(), c.data_ptr(), n + cpad, m, n, k, 1, 0, 0, 0, 0, 0, 0, 0, s)
         assert st == 0, lib.casync_last_error()
     line = f"M={m:7d} N={n:5d} K={k:5d} |"
     for opts in sets:
