@@ -76,6 +76,7 @@ _PROTOS = {
                                             C.c_void_p]),
     "casync_op_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "casync_op_audio_windows": (C.c_int, [c_f32p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "casync_op_crop_to_input": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.c_void_p]),
     "casync_op_pred_to_u8": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_void_p]),
     "casync_frame_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, c_f32p, C.c_void_p]),
@@ -88,7 +89,7 @@ _PROTOS = {
 }
 
 EXPORTS = tuple(_PROTOS)
-ABI_VERSION = 5          # == CASYNC_ABI_VERSION of include/casync_hip.h this file was written against
+ABI_VERSION = 6          # == CASYNC_ABI_VERSION of include/casync_hip.h this file was written against
 
 
 def lib_path() -> str:

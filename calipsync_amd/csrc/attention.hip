@@ -205,7 +205,9 @@ int launch_cross_attention(const void* q, int ldq, const void* k, int ldk, const
                      ld_res >= CV && ld_out >= CV,
                  "cross_attention: bad leading dimensions");
   CASYNC_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0, "cross_attention: Q/K alignment");
-  if (dtype == DT_BF16 && casync_opts().att_bf16)   // the bf16 engine's own kernel: both products on bf16 matrix instructions
+  // the bf16 engine's own kernel: both products on bf16 matrix instructions, one workgroup per frame (no channel split);
+  // a forced `att_nz` asks for the split kernel below, in bf16 too
+  if (dtype == DT_BF16 && casync_opts().att_bf16 && casync_opts().att_nz == 0)
     return launch_cross_attention_bf16(q, ldq, k, ldk, v, ldv, res, ld_res, gamma_dev, out, ld_out, batch, stream);
   static unsigned long long once_f32 = 0, once_bf16 = 0;
   if (int st = dtype == DT_BF16

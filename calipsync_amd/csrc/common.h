@@ -253,7 +253,8 @@ int launch_ir_fused(const void* in, int ld_in, const void* w1, const float* b1, 
 // expand 1x1 + depthwise 3x3 of a low-resolution inverted residual in one kernel (pw_dw.hip): fp32, 10x10 / 16x16 /
 // 20x20 frames; a [frames*hw*hw, lda], w1 [cexp][cin], wd [9][cexp], d [frames*ho*ho, ldd]
 bool pw_dw_supported(int hw, int cin, int cexp, int stride);
-const char* pw_dw_kernel_name(int hw, int cexp, int frames, int stride = 1);
+const char* pw_dw_kernel_name(int hw, int cin, int frames, int stride = 1);
+bool pw_dw_deep(int hw, int frames, int stride, bool ups, int cin);   // the launch takes the deep-ring one-frame tiles
 // ups (optional): low-resolution addend [frames*(hw/2)^2, ld_ups] whose bilinear x2 upsample is added before the first
 // activation (an Up block's upsampled half, see GemmEpilogue::ups_src)
 int launch_pw_dw(const void* a, int lda, const void* w1, const float* b1, const float* wd, const float* bd, void* d, int ldd,
@@ -280,6 +281,8 @@ int launch_crop_to_input(const unsigned char* crops, float* x, int batch, hipStr
 int launch_pred_to_u8(const float* pred, unsigned char* out, int batch, hipStream_t stream);
 int launch_audio_window_gather(const float* features, int n_steps, const int* idx_dev, void* out, int batch,
                                hipStream_t stream, int dtype = DT_F32);
+int launch_audio_windows_nchw(const float* features, int n_steps, const int* idx_dev, float* out, int batch,
+                              hipStream_t stream);
 int launch_inc(const float* x_nchw, const float* packed_inc, void* out, int ldc, int batch,
                hipStream_t stream, int dtype = DT_F32);
 int launch_outc(const void* in, int ld_in, const float* w, const float* b, float* out_nchw,

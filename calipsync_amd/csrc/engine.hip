@@ -487,12 +487,12 @@ struct Plan {
     }
     // (from fuse_dw_min = 12 frames per launch: below that its whole-frame tiles are too few to fill the chip -- B=1 0.92 vs 0.82 ms)
     // (below fuse_dw_deep frames per launch -- round 5 -- the stride-1 blocks take its one-frame tiles with a four-stage ring)
-    const bool deep = b.hw_in <= 16 && b.stride == 1 && !ups.p && B >= 2 && B < o.fuse_dw_deep;
+    const bool deep = pw_dw_deep(b.hw_in, B, b.stride, ups.p != nullptr, k_in);
     if (dt() == DT_F32 && o.fuse_dw && (b.hw_in < 40 || o.fuse_dw >= 2) && (deep || B >= (b.hw_in == 40 ? o.fuse_dw_min40 : o.fuse_dw_min)) &&
         pw_dw_supported(b.hw_in, k_in, b.cexp(), b.stride)) {
       // expand GEMM whose output tile is whole frames: the depthwise conv runs on the tile in LDS, E never exists
       // (flops: what this launch executes -- with `ups` the upsampled half was a GEMM at the low resolution)
-      r.run((p + ".pw1dw").c_str(), pw_dw_kernel_name(b.hw_in, b.cexp(), B, b.stride),
+      r.run((p + ".pw1dw").c_str(), pw_dw_kernel_name(b.hw_in, k_in, B, b.stride),
             2.0 * (m_in * (double)k_in * b.cexp() + 9.0 * m_out * b.cexp()),
             4.0 * (m_in * (double)k_in + (double)b.cexp() * k_in + (double)m_out * b.cexp()), [&] {
         return launch_pw_dw(in, ld_in, e.W(w1name), e.W(p + ".pw1.b"), e.W(p + ".dw.w"), e.W(p + ".dw.b"), e2,
@@ -1290,6 +1290,12 @@ int casync_op_nchw_to_nhwc(const float* in, void* out, int batch, int c, int hw,
 int casync_op_inc(const float* x_nchw, const float* packed_inc, void* out, int ldc, int batch,
                   casync_stream stream) {
   return launch_inc(x_nchw, packed_inc, out, ldc, batch, (hipStream_t)stream, g_op_dtype);
+}
+int casync_op_audio_windows(const float* features_dev, int n_steps, const int32_t* frame_idx_dev, void* windows_dev,
+                            int batch, int nhwc, casync_stream stream) {
+  if (nhwc) return launch_audio_window_gather(features_dev, n_steps, frame_idx_dev, windows_dev, batch, (hipStream_t)stream,
+                                              g_op_dtype);
+  return launch_audio_windows_nchw(features_dev, n_steps, frame_idx_dev, (float*)windows_dev, batch, (hipStream_t)stream);
 }
 int casync_op_crop_to_input(const uint8_t* crops168_dev, float* x_dev, int batch, casync_stream stream) {
   return launch_crop_to_input(crops168_dev, x_dev, batch, (hipStream_t)stream);

@@ -175,6 +175,8 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
   using G = IRGeom<CIN, COUT, STRIDE, CC, UPG>;
   constexpr int NCH = CE / CC;
   static_assert(CC == 16, "e_off() keys and the E row padding are worked out for 64-B pixels");
+  static_assert(sizeof(T) == 4, "the buffer-addressed A loads, the residual load and the accumulator store assume fp32 rows "
+                                "(bf16 has its own kernel, ir_fused_bf16_kernel)");
   static_assert(NCH % 2 == 0 && NCH >= 2, "the chunk loop is unrolled over the buffer parity");
   static_assert(!UPG || (STRIDE == 1 && sizeof(T) == 4), "the commuted form exists for the fp32 stride-1 Up blocks");
   static_assert(G::total * 4 <= 160 * 1024, "LDS budget");

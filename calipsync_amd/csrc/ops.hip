@@ -282,7 +282,9 @@ __host__ __device__ inline AudioWindow audio_window_plan(int idx, int T) {
   return AudioWindow{start, n0, pl, n1 + pr == 16};
 }
 
-template <typename T>
+// NCHW = false: the engine's NHWC image [B][1024 pixels][32 channels] in its storage type (thread = 4 channels of a pixel);
+// NCHW = true : the reference's own array [B][32][32][32] fp32 (thread = the same 4 channels, stored to 4 planes).
+template <typename T, bool NCHW = false>
 __global__ __launch_bounds__(256) void audio_window_gather_kernel(const float* __restrict__ feat, int n_steps,
                                                                   const int* __restrict__ idx,
                                                                   T* __restrict__ out, long long total) {
@@ -305,7 +307,15 @@ __global__ __launch_bounds__(256) void audio_window_gather_kernel(const float* _
       v.w = feat[(size_t)(w.start + r1) * 2048 + 1024 + p];
     }
   }
-  st4(out + ((size_t)b * 1024 + p) * 32 + c, v);
+  if constexpr (NCHW) {
+    T* o = out + ((size_t)b * 32 + c) * 1024 + p;
+    o[0] = (T)v.x;
+    o[1024] = (T)v.y;
+    o[2048] = (T)v.z;
+    o[3072] = (T)v.w;
+  } else {
+    st4(out + ((size_t)b * 1024 + p) * 32 + c, v);
+  }
 }
 
 // ---------------------------------------------------------------- frame-loop tensor glue
@@ -631,6 +641,16 @@ int launch_audio_window_gather(const float* features, int n_steps, const int* id
                                  features, n_steps, idx_dev, (float*)out, total),
               hipLaunchKernelGGL(audio_window_gather_kernel<bf16_t>, dim3(blocks_for(total)), dim3(256), 0, stream,
                                  features, n_steps, idx_dev, (bf16_t*)out, total));
+  CASYNC_CHECK_HIP(hipGetLastError());
+  return CASYNC_OK;
+}
+
+int launch_audio_windows_nchw(const float* features, int n_steps, const int* idx_dev, float* out, int batch,
+                              hipStream_t stream) {
+  CASYNC_REQUIRE(features && idx_dev && out && batch > 0 && n_steps > 0, "audio_windows: bad args");
+  const long long total = (long long)batch * 8 * 1024;
+  hipLaunchKernelGGL((audio_window_gather_kernel<float, true>), dim3(blocks_for(total)), dim3(256), 0, stream, features,
+                     n_steps, idx_dev, out, total);
   CASYNC_CHECK_HIP(hipGetLastError());
   return CASYNC_OK;
 }

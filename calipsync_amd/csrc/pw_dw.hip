@@ -453,6 +453,8 @@ int launch_fs(const float* a, int lda, const float* w1, const float* b1, const f
   const long long nwg = (long long)frames * G::NS * n_nt;
   const unsigned long long ab = ((unsigned long long)((long long)frames * G::P - 1) * lda + k) * 4, wb = (unsigned long long)n * k * 4;
   CASYNC_REQUIRE(nwg < (1ll << 31) && ab < (1ull << 31) && wb < (1ull << 31), "pw_dw: operand larger than 2 GiB");
+  CASYNC_REQUIRE((long long)frames * G::P < (1ll << 24) && (long long)lda * 4 < (1ll << 24),
+                 "pw_dw: %lld rows of %d floats exceed the kernel's 24-bit row arithmetic", (long long)frames * G::P, lda);
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), G::lds + (ups ? kUpsTileBytes : 0), stream, a, lda, w1, b1, wd, bd, d, ldd, frames, k, n, n_nt,
                      (int)nwg, (unsigned)ab, (unsigned)wb, ups, ld_ups);
   CASYNC_CHECK_HIP(hipGetLastError());
@@ -472,6 +474,8 @@ int launch_ft(const float* a, int lda, const float* w1, const float* b1, const f
   const long long nwg = (long long)n_ft * n_nt;
   const unsigned long long ab = ((unsigned long long)((long long)frames * G::P - 1) * lda + k) * 4, wb = (unsigned long long)n * k * 4;
   CASYNC_REQUIRE(nwg < (1ll << 31) && ab < (1ull << 31) && wb < (1ull << 31), "pw_dw: operand larger than 2 GiB");
+  CASYNC_REQUIRE((long long)frames * G::P < (1ll << 24) && (long long)lda * 4 < (1ll << 24),
+                 "pw_dw: %lld rows of %d floats exceed the kernel's 24-bit row arithmetic", (long long)frames * G::P, lda);
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), G::lds + (ups ? kUpsTileBytes : 0), stream, a, lda, w1, b1, wd, bd, d, ldd, frames, k, n, n_nt,
                      (int)nwg, (unsigned)ab, (unsigned)wb, ups, ld_ups);
   CASYNC_CHECK_HIP(hipGetLastError());
@@ -488,15 +492,15 @@ bool pw_dw_supported(int hw, int cin, int cexp, int stride) {
 
 // the deep-ring instances serve launches of 2 .. `fuse_dw_deep` - 1 frames (10x10 / 16x16, stride 1, no upsampled addend):
 // measured B=4 -1.2 %, B=8 -2.3 %; B=1 +1.1 %, B=11 +1.4 % (profiles/r5_ab_small_batch.txt)
-static bool pw_dw_deep(int hw, int frames, int stride, bool ups) {
-  return hw <= 16 && stride == 1 && !ups && frames >= 2 && frames < casync_opts().fuse_dw_deep;
+// (their k-tiles are 32 input channels wide: cin % 32, or the last 16 channels would be dropped -- ADVICE r5)
+bool pw_dw_deep(int hw, int frames, int stride, bool ups, int cin) {
+  return hw <= 16 && stride == 1 && !ups && cin % 32 == 0 && frames >= 2 && frames < casync_opts().fuse_dw_deep;
 }
 
-const char* pw_dw_kernel_name(int hw, int cexp, int frames, int stride) {
+const char* pw_dw_kernel_name(int hw, int cin, int frames, int stride) {
   static thread_local char buf[64];
-  (void)cexp;
   if (hw == 40) snprintf(buf, sizeof(buf), "pw_dw_strip_kernel<40, %d, %d, 32, 16>", stride == 1 ? 8 : 4, stride);
-  else if (pw_dw_deep(hw, frames, stride, false)) snprintf(buf, sizeof(buf), "pw_dw_kernel<%d, 1, 32, 32, 1, %d>", hw, hw == 10 ? 4 : 3);
+  else if (pw_dw_deep(hw, frames, stride, false, cin)) snprintf(buf, sizeof(buf), "pw_dw_kernel<%d, 1, 32, 32, 1, %d>", hw, hw == 10 ? 4 : 3);
   else snprintf(buf, sizeof(buf), "pw_dw_kernel<%d, %d, 32, 16, %d, 2>", hw, hw == 10 ? 2 : 1, stride);
   return buf;
 }
@@ -521,7 +525,7 @@ int launch_pw_dw(const void* a, int lda, const void* w1, const float* b1, const 
                        : launch_fs<40, 4, 2, 32, 16>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);
   // small launches (round 5): one frame per tile, 128-B k-tile rows and a four-stage (16x16: three-stage) ring -- twice
   // the workgroups, half the k-iterations, three k-tiles in flight
-  const bool deep = pw_dw_deep(hw, frames, stride, ups != nullptr);
+  const bool deep = pw_dw_deep(hw, frames, stride, ups != nullptr, cin);
   if (hw == 10)
     return deep ? launch_ft<10, 1, 32, 32, 1, 4>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream)
                 : launch_ft<10, 2, 32, 16, 1>(af, lda, wf, b1, wd, bd, df, ldd, frames, cin, cexp, uf, ld_ups, stream);

@@ -469,6 +469,8 @@ int launch_common(Kern kern, unsigned long long* attr_once, bool ups_ok, long lo
   if (int st = casync_ensure_dyn_lds(attr_once, reinterpret_cast<const void*>(kern), (int)G::lds + (ups_ok ? kUpsTileBytes : 0))) return st;
   const unsigned long long ab = ((unsigned long long)((long long)frames * G::P - 1) * lda + k) * 2, wb = (unsigned long long)n * k * 2;
   CASYNC_REQUIRE(nwg < (1ll << 31) && ab < (1ull << 31) && wb < (1ull << 31), "pw_dw (bf16): operand larger than 2 GiB");
+  CASYNC_REQUIRE((long long)frames * G::P < (1ll << 24) && (long long)lda * 2 < (1ll << 24),
+                 "pw_dw (bf16): %lld rows of %d elements exceed the kernel's 24-bit row arithmetic", (long long)frames * G::P, lda);
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), G::lds + (ups ? kUpsTileBytes : 0), stream, a, lda, w1, b1, wd, bd, d, ldd, frames,
                      k, n, n_nt, (int)nwg, (unsigned)ab, (unsigned)wb, ups, ld_ups);
   CASYNC_CHECK_HIP(hipGetLastError());

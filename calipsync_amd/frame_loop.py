@@ -10,7 +10,7 @@ csrc/frame_ops.hip), with one upload and one download per batch:
 
 * ``submit_batch_device`` / ``PendingBatch.result`` -- the asynchronous pair (one batch can be in flight
   while the next is prepared), ``process_batch_device`` -- both in one call;
-* ``crops_to_model_input`` / ``predictions_to_uint8`` -- the two pure-indexing pieces on their own;
+* ``crops_to_model_input`` / ``predictions_to_uint8`` / ``audio_windows_device`` -- the pure-indexing pieces on their own;
 * ``audio_windows_host`` / ``crop_box`` -- the host-side restatements the device path is tested against.
 
 The OpenCV arithmetic is restated bit for bit from its published algorithms (oracle/frame_ops_oracle.py);
@@ -62,6 +62,32 @@ def predictions_to_uint8(pred: torch.Tensor) -> torch.Tensor:
         with torch.cuda.device(pred.device):
             _lib.check(_lib.load().casync_op_pred_to_u8(pred.data_ptr(), out.data_ptr(), b, _stream(pred.device)),
                        "pred_to_u8")
+    return out
+
+
+def audio_windows_device(features: torch.Tensor, frame_indices) -> torch.Tensor:
+    """``FrameSynthesizer._get_audio_features`` (infer_api.py:99-145) on the device: ``features`` [T,2,1024] fp32 on a
+    ROCm device (the clip's HuBERT features, uploaded once), ``frame_indices`` a sequence of ints or an int32 device
+    tensor -> the reference's own return value [B,32,32,32] fp32, on the device (``casync_op_audio_windows``).
+    ``Model.forward_windows`` runs the same gather inside the forward; this is the operator on its own."""
+    if features.dtype != torch.float32 or features.dim() != 3 or tuple(features.shape[1:]) != (2, 1024):
+        raise RuntimeError(f"features must be float32 [T,2,1024], got {features.dtype} {tuple(features.shape)}")
+    if features.device.type != "cuda":
+        raise RuntimeError("features must be on a ROCm device (no CPU fallback)")
+    if features.shape[0] < 1:
+        raise RuntimeError("features holds no step")
+    features = features.contiguous()
+    if torch.is_tensor(frame_indices):
+        idx = frame_indices.to(device=features.device, dtype=torch.int32).contiguous()
+    else:
+        idx = torch.tensor([int(i) for i in frame_indices], dtype=torch.int32).to(features.device)
+    b = idx.numel()
+    out = torch.empty((b, 32, 32, 32), dtype=torch.float32, device=features.device)
+    if b:
+        with torch.cuda.device(features.device):
+            _lib.check(_lib.load().casync_op_audio_windows(features.data_ptr(), features.shape[0], idx.data_ptr(),
+                                                           out.data_ptr(), b, 0, _stream(features.device)),
+                       "audio_windows")
     return out
 
 

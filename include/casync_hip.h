@@ -43,7 +43,7 @@ enum {
 /* ---- introspection (callable without a GPU) --------------------------- */
 /* Bumped on every change of a prototype, struct layout or the packed-weight layout; the ctypes
  * host (calipsync_amd/_lib.py) refuses a library whose version differs from the one it binds.   */
-#define CASYNC_ABI_VERSION 5
+#define CASYNC_ABI_VERSION 6
 int         casync_abi_version(void);
 const char* casync_last_error(void);           /* thread-local message         */
 
@@ -219,6 +219,14 @@ int casync_op_cross_attention(const void* q, int ldq, const void* k, int ldk,
                               const void* v, int ldv, const void* res, int ld_res,
                               const float* gamma_dev, void* out, int ld_out,
                               int batch, casync_stream stream);
+/* FrameSynthesizer._get_audio_features (infer_api.py:99-145) alone, on the device: the gather casync_forward_windows
+ * starts with, as an operator.  features_dev [n_steps,2,1024] fp32, frame_idx_dev [batch] int32 (any value: negative,
+ * past the end).  nhwc = 0: windows_dev is the reference's own return value, [batch,32,32,32] fp32 (window row r of
+ * features[idx-8 : idx+8] = channels 2r, 2r+1; all zeros where the reference falls back to its default window);
+ * nhwc = 1: the engine's image [batch,1024,32] in the storage type of casync_op_set_dtype (what the first audio
+ * kernel reads).  Bit-exact against the reference's own output (tests/golden/frame_windows.npz).                    */
+int casync_op_audio_windows(const float* features_dev, int n_steps, const int32_t* frame_idx_dev, void* windows_dev,
+                            int batch, int nhwc, casync_stream stream);
 /* Tensor glue of FrameSynthesizer.process_batch around the model call, on the device:
  * crop_to_input: resized 168x168 BGR crops (uint8 HWC) -> the [B,6,160,160] fp32 model input
  *   (inner [4:164,4:164], masked copy with the black rectangle (5,5,150,145), HWC->CHW, /255,

@@ -5,6 +5,16 @@ import os
 import numpy as np
 
 
+def golden_features(t: int, seed: int = 3) -> np.ndarray:
+    """The [t, 2, 1024] fp32 feature arrays behind tests/golden/frame_windows.npz, values in [-1, 1): 24 hashed bits
+    per value and exact arithmetic only (integer hashing, one exact int->float conversion, one division by 2^23), so
+    every box regenerates the same bits; the fixture carries their SHA-256."""
+    from calipsync_amd import recipe
+    bits = recipe._bits(seed, 0x77696E, t * 2048, lane=t)
+    v = (bits >> np.uint64(40)).astype(np.int64) - (1 << 23)
+    return (v.astype(np.float32) / np.float32(1 << 23)).reshape(t, 2, 1024)
+
+
 def landmarks(cx: float, cy: float, r: float, rng, jitter: float = 1.5) -> np.ndarray:
     """110 x 2 float landmarks: points 0..32 run along the lower face contour from the left temple over the
     chin to the right temple; point 52 sits above the mouth (its y is the crop's top), points 1 and 31 give

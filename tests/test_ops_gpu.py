@@ -422,6 +422,7 @@ def test_ir_fused_with_commuted_upsample(lib, recipe_sd, prefix, cin, h, w, b):
 @pytest.mark.parametrize("hw,stride,cin,cexp,frames", [
     (10, 1, 512, 1024, 5), (10, 1, 1024, 2048, 2), (10, 1, 256, 512, 33), (16, 1, 256, 512, 3), (20, 1, 256, 512, 2),
     (20, 2, 256, 512, 3), (20, 1, 128, 256, 2), (10, 1, 64, 128, 1),
+    (10, 1, 48, 96, 4), (16, 1, 16, 32, 2),        # cin % 32 != 0 at 2..9 frames: NOT the deep ring's 32-channel k-tiles
     (40, 1, 128, 256, 3), (40, 2, 128, 256, 2), (40, 1, 16, 32, 1), (40, 2, 64, 128, 17)])
 def test_pw_dw_fused(lib, hw, stride, cin, cexp, frames):
     """Expand 1x1 + LeakyReLU + depthwise 3x3 + LeakyReLU in one kernel (pw_dw.hip) vs plain PyTorch: odd frame
