@@ -160,3 +160,36 @@ def test_round3_line_carries_the_secondary_block():
     assert set(sec) >= {"b8_fp32", "e2e", "bf16_b512"}
     assert "NOT the parity path" in sec["bf16_b512"]["dtype"] and sec["bf16_b512"]["roofline"]["frac"] > 0
     assert sec["b8_fp32"]["batch"] == 8 and sec["e2e"]["frames_per_s"] > 0 and sec["e2e"]["frames_per_s_with_masks"] > 0
+
+
+R6 = [("r6_bench.json", "r6_pmc_traffic.json", "r6_mfma_busy.json", "r6_f32_b64_kernel_stats_replay"),
+      ("r6_bench_bf16_b512.json", "r6_pmc_traffic_bf16_b512.json", "r6_mfma_busy_bf16_b512.json",
+       "r6_bf16_b512_kernel_stats_replay")]
+
+
+@pytest.mark.parametrize("bench,traffic,busy,stats", R6)
+def test_round6_profiles_reproduce_the_line(bench, traffic, busy, stats):
+    """Round 6: the round-4 contract on ONE collection (`tools/collect_profiles.sh r6 f32|bf16`)."""
+    test_round4_profiles_reproduce_the_line(bench, traffic, busy, stats)
+
+
+@pytest.mark.parametrize("bench,traffic", [(R6[0][0], R6[0][1]), (R6[1][0], R6[1][1])])
+def test_round6_lines_report_the_bytes_the_engine_moves(bench, traffic):
+    """VERDICT r5 #2 / SURVEY 8(d): the roofline at the granularity the kernels implement.  `whole_net.hbm_bytes_moved_per_frame`
+    = sum over the step's kernels of the PMC pass's HBM bytes per launch x launches / frames; a fused engine moves FEWER bytes
+    than the canonical un-fused network, so `hbm_frac_moved <= hbm_frac_canonical`; and the dominant kernel's share is named
+    for what it is (`share_of_replay`)."""
+    for f in (bench, traffic):
+        if not os.path.exists(os.path.join(PROF, f)):
+            pytest.skip(f"profiles/{f} not collected yet")
+    line = json.load(open(os.path.join(PROF, bench)))
+    wn = line["whole_net"]
+    assert wn["hbm_bytes_moved_per_frame"] and 0 < wn["hbm_frac_moved"] <= wn["hbm_frac_canonical"] < 1
+    assert wn["hbm_bytes_moved_per_frame"] < wn["canonical_mb_per_frame"] * 1e6
+    assert "share_of_replay" in line["roofline"] and "share_of_step" not in line["roofline"]
+    # recompute: per_gpu frames/s x bytes / 8 TB/s
+    assert abs(line["value"] / line["n_gpus"] * wn["hbm_bytes_moved_per_frame"] / 8e12 - wn["hbm_frac_moved"]) < 2e-3
+    if "secondary" in line:
+        w16 = line["secondary"]["bf16_b512"]["whole_net"]
+        assert 0 < w16["hbm_frac_moved"] <= w16["hbm_frac_canonical"] and w16["mfma_frac_executed"] > 0
+        assert "share_of_replay" in line["secondary"]["bf16_b512"]["roofline"]
