@@ -14,6 +14,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // Activation storage type of an engine / operator call.  Arithmetic is always fp32
 // (accumulate, bias, activation, softmax); DT_BF16 stores activations and feeds the matrix
@@ -105,6 +106,9 @@ struct CasyncOptions {
   int ups_commute_bf16 = 1;  // CASYNC_UPS_COMMUTE_BF16: up1.0 / up2.0 of the bf16 engine run the upsampled half of their expand conv at the low
                              //   resolution and pw_dw_bf16 adds its upsample (needs fuse_dw_bf16 >= 2 and >= fuse_dw_bf16_min frames per launch)
   int fuse_dw_bf16_min = 12; // CASYNC_FUSE_DW_BF16_MIN: frames per launch from which it is used
+  int ir_dw_mfma = 1;        // CASYNC_IR_DW_MFMA: the bf16 fused inverted-residual block runs its depthwise 3x3 on the matrix pipe (block-diagonal
+                             //   v_mfma_f32_16x16x32_bf16, taps rounded to bf16): 1 = in the instances where that measured faster (all but
+                             //   up4.0's 64 -> 128 -> 32), 2 = in all, 0 = the VALU form with fp32 taps (round 5)
   int dw_lds = 1;            // CASYNC_DW_LDS: LDS-slab depthwise kernel
   int dw_lds_bytes = 32768;  // CASYNC_DW_LDS_BYTES
   int att_nz = 0;            // CASYNC_ATT_NZ: channel split of the attention kernel (0 = by batch)

@@ -662,7 +662,8 @@ __device__ __forceinline__ f32x4 mfma16b(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int CIN, int CE, int COUT, int STRIDE, bool UPS>
+// DWM (round 6): the depthwise phase on the matrix pipe -- see P2 below.
+template <int CIN, int CE, int COUT, int STRIDE, bool UPS, bool DWM>
 __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void ir_fused_bf16_kernel(
     const bf16_t* __restrict__ lo, int ld_lo, int c_lo, const bf16_t* __restrict__ in, int ld_in,
     const bf16_t* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ wd,
@@ -738,6 +739,19 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
   stage_a(0, 0);
   if (NCH > 1) stage_a(1, 1);
   stage_b(0, 0);
+  // DWM: the block-diagonal A fragments of the depthwise MFMAs.  Lane (q, m) of fragment (tap pair u, tile h) holds K-slots
+  // j = 0..7 = physical channels 8 (q & 1) + j of tap 2 u + (q >> 1); the only non-zero one is row m's channel (when
+  // m >> 3 == q & 1): dword (m & 7) >> 1, half m & 1, value wd[tap][logical channel 8 (m >> 2) + 4 h + (m & 3)] as bf16 -- the
+  // tap word (both halves) ANDed with these four lane masks.
+  unsigned amask[4];
+  int wtap_off = 0;              // float offset of this lane's weight in the chunk's taps block: tap (q >> 1), channel of row l15, h = 0
+  if constexpr (DWM) {
+    const bool act = (l15 >> 3) == (q & 1);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) amask[d] = act && d == ((l15 & 7) >> 1) ? ((l15 & 1) ? 0xFFFF0000u : 0x0000FFFFu) : 0u;
+    wtap_off = (q >> 1) * 32 + 8 * (l15 >> 2) + (l15 & 3);
+  }
+
   // ---- A fragments of this wave's halo rows: HBM -> registers, once.  Round 5: the tile index is a scalar (wave_s), every
   //      access is a buffer access with a 32-bit lane offset (a pixel outside the image = an offset past the end = zeros), and
   //      the on-the-fly bilinear x2 of the Up blocks is a weighted sum of its four corners with packed fused multiply-adds
@@ -805,6 +819,27 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
   const char* ebk[3];
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx) ebk[kx] = sE + 4 * e_off<STRIDE, 16, G::IW>(G::MT3 * wave * STRIDE, l15 * STRIDE + kx, q);
+  // DWM: the five tap pairs.  Lane (q, pixel l15) supplies, as the MFMA B operand, eight channels of tap t = 2 u + (q >> 1)
+  // of its pixel: 16-B column 2 h + (q & 1) of halo pixel (row + ky(t), column + kx(t)).  Tap 9 does not exist (weight 0):
+  // its lanes read tap 8's pixel (finite values).  (The h = 1 address is the h = 0 address +- 32 bytes, but the sign follows
+  // the XOR key of e_off(), i.e. the tap's kx: both are kept.)
+  const char* ebu[5][2];
+  // DWM: E's channels are stored PERMUTED inside a pixel -- logical channel c = 8 a + 4 b + i sits at physical position
+  // 16 b + 4 a + i (P1 writes them there at no cost) -- so that the rows 4 q .. 4 q + 3 a lane gets back from tile h (physical
+  // channels 16 h + 4 q + i) are logical channels 8 q + 4 h + i: over both tiles the lane holds the eight CONSECUTIVE channels
+  // 8 q .. 8 q + 7 of its pixel, P3's B operand in the k order W2c is staged in (one 16-byte read per W2c fragment; the
+  // first build read W2c in two 8-byte halves instead: 2-way bank conflicts, 0.09 -> 0.29-0.43 of the LDS cycles).
+  if constexpr (DWM) {
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      int t = 2 * u + (q >> 1);
+      t = t > 8 ? 8 : t;
+      const int ky = t / 3, kx = t - 3 * ky;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        ebu[u][h] = sE + 4 * e_off<STRIDE, 16, G::IW>(G::MT3 * wave * STRIDE + ky, l15 * STRIDE + kx, 2 * h + (q & 1));
+    }
+  }
 
 #pragma unroll 1
   for (int ch = 0; ch < NCH; ++ch) {
@@ -845,8 +880,9 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
 #pragma unroll
           for (int n = 0; n < 2; ++n) {   // channels 16 n + 4 q .. + 3 = half (q & 1) of 16-B column 2 n + (q >> 1)
             const f32x4 a = inside ? lrelu4(acc[i][n]) : f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<bf16x4*>(sE + 4 * e_off<STRIDE, 16, G::IW>(hy, hx, 2 * n + (q >> 1)) + 8 * (q & 1)) =
-                __builtin_convertvector(a, bf16x4);
+            // (DWM: the permuted pixel -- c = 8 a' + 4 b + i at 16 b + 4 a' + i: a' = 2 n + (q >> 1), b = q & 1 -> column 2 b + n, half q >> 1)
+            const int col = DWM ? 2 * (q & 1) + n : 2 * n + (q >> 1), half = DWM ? (q >> 1) : (q & 1);
+            *reinterpret_cast<bf16x4*>(sE + 4 * e_off<STRIDE, 16, G::IW>(hy, hx, col) + 8 * half) = __builtin_convertvector(a, bf16x4);
           }
         }
       }
@@ -863,7 +899,67 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
     //      stays in registers (round 4; the tap rows of the stacked pixels are shared: 12 instead of 18 E reads) ----
     constexpr int NPX = G::MT3, NROW = (NPX - 1) * STRIDE + 3, EROWB = G::IW * 64 + 16;
     bf16x8 fd[NPX];
-    {
+    if constexpr (DWM) {
+      // ---- P2 on the matrix pipe (round 6; VERDICT r5 #3, tools/experiments/ubench/dw_mfma_bf16.hip).  The VALU form below
+      //      widens every E value to fp32, multiplies and narrows -- ~200 of the chunk's ~260 vector instructions per wave
+      //      while the bf16 matrix pipe idles.  Here D[c][p] = sum_t wd[t][c] E[p + t][c] is a GEMM with a BLOCK-DIAGONAL A:
+      //      output tile = 16 channels (rows) x 16 pixels (columns), K = 2 taps x 16 channels,
+      //         A[m][(tap, c')] = wd[tap][16 h + m] * (c' == m),    B[(tap, c')][n] = E[pixel n + tap][16 h + c'],
+      //      so a lane's B operand is ONE 16-byte read of the E image as it stands (no widening), nine taps are five MFMAs
+      //      per tile (tap 9: weight 0), bias is the accumulator's initial value, LeakyReLU + narrowing run on 8 values per
+      //      lane and pixel instead of 72 products.  The A fragment of lane (q, m) has one non-zero K-slot (channel m of
+      //      its tap, when m >> 3 == q & 1): the tap rounded to bf16 in both halves of a dword, ANDed with four lane
+      //      masks.  Taps enter the product as bf16 (the VALU form keeps them fp32): D's mean error grows from 4.5e-4 to
+      //      6.1e-4 of |D| ~ 0.32 in the microbenchmark; the network's error bars are what the tests hold.
+      //      The lane ends up with rows 4 q .. 4 q + 3 of both tiles = channels {4 q + i} and {16 + 4 q + i} of pixel l15:
+      //      P3 reads W2c's K in that order. ----
+      f32x4 acc[NPX][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(wf + 10 * 32 + 8 * q + 4 * h);   // rows 4 q + i of tile h = channels 8 q + 4 h + i
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) acc[j][h] = bias;
+      }
+      // Ten steps st = (tap pair u, tile h), h alternating so that the four accumulators (NPX x 2) form independent chains.
+      // The ten tap words are read first (LDS returns in order: a tap read between two B requests would make its wait a wait
+      // for the younger B request as well), then the B fragments are requested a step ahead into a second set of registers:
+      // left to itself the compiler reuses one register set and waits for every step's LDS reads in front of its MFMAs.
+      unsigned wwq[10];
+#pragma unroll
+      for (int st = 0; st < 10; ++st) {
+        float w = wf[wtap_off + 2 * (st >> 1) * 32 + 4 * (st & 1)];   // (u = 4, upper lane half: row 9 of the block is b1, not a tap)
+        if ((st >> 1) == 4) w = (q >> 1) ? 0.f : w;
+        const bf16x4 wb2 = __builtin_convertvector(f32x4{w, w, 0.f, 0.f}, bf16x4);
+        wwq[st] = __builtin_bit_cast(unsigned, bf16x2{wb2[0], wb2[1]});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      auto ld_b = [&](int st, int j) {
+        return *reinterpret_cast<const bf16x8*>(ebu[st >> 1][st & 1] + j * STRIDE * EROWB);
+      };
+      bf16x8 fbq[2][NPX];
+#pragma unroll
+      for (int j = 0; j < NPX; ++j) fbq[0][j] = ld_b(0, j);
+#pragma unroll
+      for (int st = 0; st < 10; ++st) {
+        const int h = st & 1;
+        if (st + 1 < 10) {
+#pragma unroll
+          for (int j = 0; j < NPX; ++j) fbq[(st + 1) & 1][j] = ld_b(st + 1, j);
+        }
+        const unsigned ww = wwq[st];
+        const bf16x8 fa_d = __builtin_bit_cast(bf16x8, u32x4{ww & amask[0], ww & amask[1], ww & amask[2], ww & amask[3]});
+        __builtin_amdgcn_sched_barrier(0);      // the requests above stay above this step's MFMAs
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) acc[j][h] = mfma16b(fa_d, fbq[st & 1][j], acc[j][h]);
+      }
+#pragma unroll
+      for (int j = 0; j < NPX; ++j) {
+        const f32x4 l0 = lrelu4(acc[j][0]), l1 = lrelu4(acc[j][1]);
+        const bf16x4 h0 = __builtin_convertvector(l0, bf16x4), h1 = __builtin_convertvector(l1, bf16x4);
+        fd[j] = bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};   // channels 8 q .. 8 q + 7 of pixel l15
+      }
+    } else {
+
       const int c8 = 8 * q;
       f32x4 a0[NPX], a1[NPX];
 #pragma unroll
@@ -914,8 +1010,10 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
     {
       bf16x8 fb[G::NT3];
 #pragma unroll
-      for (int n = 0; n < G::NT3; ++n)
-        fb[n] = *reinterpret_cast<const bf16x8*>(wb + GB::wW2 + xsb<64>(32 * (n >> 1) + 8 * (l15 >> 2) + 4 * (n & 1) + (l15 & 3), 16 * q));
+      for (int n = 0; n < G::NT3; ++n) {
+        const int row = 32 * (n >> 1) + 8 * (l15 >> 2) + 4 * (n & 1) + (l15 & 3);
+        fb[n] = *reinterpret_cast<const bf16x8*>(wb + GB::wW2 + xsb<64>(row, 16 * q));
+      }
 #pragma unroll
       for (int i = 0; i < G::MT3; ++i)
 #pragma unroll
@@ -952,14 +1050,14 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
   }
 }
 
-template <int CIN, int CE, int COUT, int STRIDE, bool UPS>
+template <int CIN, int CE, int COUT, int STRIDE, bool UPS, bool DWM = true>
 int launch_inst_b(const bf16_t* lo, int ld_lo, int c_lo, const bf16_t* in, int ld_in, const bf16_t* w1,
                   const float* b1, const float* wd, const float* bd, const bf16_t* w2, const float* b2,
                   bf16_t* out, int ld_out, int batch, int h, int w, int res, hipStream_t stream) {
   using GB = IRGeomB<CIN, COUT, STRIDE>;
   using G = typename GB::G;
   constexpr size_t lds = (size_t)GB::total;
-  auto kern = ir_fused_bf16_kernel<CIN, CE, COUT, STRIDE, UPS>;
+  auto kern = ir_fused_bf16_kernel<CIN, CE, COUT, STRIDE, UPS, DWM>;
   static unsigned long long attr_once = 0;
   if (int st = casync_ensure_dyn_lds(&attr_once, reinterpret_cast<const void*>(kern), (int)lds)) return st;
   const int ho = (h + 2 - 3) / STRIDE + 1, wo = (w + 2 - 3) / STRIDE + 1;
@@ -987,15 +1085,26 @@ int launch_inst_t(const T* lo, int ld_lo, int c_lo, const T* in, int ld_in, cons
   return CASYNC_OK;
 }
 
+// `ir_dw_mfma`: 1 = the depthwise phase of the bf16 kernel on the matrix pipe where that measured faster -- every instance
+// but the 64 -> 128 -> 32 block (up4.0: 1.49 -> 1.58 ms with it, profiles/r6_ab_bf16_dw_mfma.txt), 2 = everywhere, 0 = nowhere
+inline bool ir_dw_mfma_on(int cin, int cout) {
+  const int v = casync_opts().ir_dw_mfma;
+  return v >= 2 || (v == 1 && !(cin == 64 && cout == 32));
+}
+
 // w1 / w2 are in the call's storage type (fp32 or bf16); b1, wd, bd, b2 are always fp32
 template <int CIN, int CE, int COUT, int STRIDE, int CC, bool UPS = false>
 int launch_inst(int dtype, const void* lo, int ld_lo, int c_lo, const void* in, int ld_in, const void* w1,
                 const float* b1, const float* wd, const float* bd, const void* w2, const float* b2,
                 void* out, int ld_out, int batch, int h, int w, int res, hipStream_t stream) {
   if (dtype == DT_BF16)
-    return launch_inst_b<CIN, CE, COUT, STRIDE, UPS>((const bf16_t*)lo, ld_lo, c_lo, (const bf16_t*)in, ld_in,
-                                                     (const bf16_t*)w1, b1, wd, bd, (const bf16_t*)w2, b2,
-                                                     (bf16_t*)out, ld_out, batch, h, w, res, stream);
+    return ir_dw_mfma_on(CIN, COUT)
+               ? launch_inst_b<CIN, CE, COUT, STRIDE, UPS, true>((const bf16_t*)lo, ld_lo, c_lo, (const bf16_t*)in, ld_in,
+                                                                 (const bf16_t*)w1, b1, wd, bd, (const bf16_t*)w2, b2,
+                                                                 (bf16_t*)out, ld_out, batch, h, w, res, stream)
+               : launch_inst_b<CIN, CE, COUT, STRIDE, UPS, false>((const bf16_t*)lo, ld_lo, c_lo, (const bf16_t*)in, ld_in,
+                                                                  (const bf16_t*)w1, b1, wd, bd, (const bf16_t*)w2, b2,
+                                                                  (bf16_t*)out, ld_out, batch, h, w, res, stream);
   return launch_inst_t<float, CIN, CE, COUT, STRIDE, CC, UPS ? 1 : 0>((const float*)lo, ld_lo, c_lo, (const float*)in,
                                                               ld_in, (const float*)w1, b1, wd, bd, (const float*)w2,
                                                               b2, (float*)out, ld_out, batch, h, w, res, stream);
@@ -1073,7 +1182,8 @@ const char* ir_fused_upg_kernel_name(int cin, int cout) {
 const char* ir_fused_kernel_name(int cin, int cout, int stride, int dtype, bool ups, int h, int w) {
   static thread_local char buf[64];
   if (dtype == DT_BF16)
-    snprintf(buf, sizeof(buf), "ir_fused_bf16_kernel<%d, %d, %d, %d, %s>", cin, 2 * cin, cout, stride, ups ? "true" : "false");
+    snprintf(buf, sizeof(buf), "ir_fused_bf16_kernel<%d, %d, %d, %d, %s, %s>", cin, 2 * cin, cout, stride, ups ? "true" : "false",
+             ir_dw_mfma_on(cin, cout) ? "true" : "false");
   else
     snprintf(buf, sizeof(buf), "ir_fused_kernel<float, %d, %d, %d, %d, 16, %d>", cin, 2 * cin, cout, stride, ups ? 1 : 0);
   return buf;

@@ -39,6 +39,7 @@ const OptField kFields[] = {
     {"fuse_dw_min40", &CasyncOptions::fuse_dw_min40},
     {"fuse_dw_deep", &CasyncOptions::fuse_dw_deep},
     {"att_bf16", &CasyncOptions::att_bf16},
+    {"ir_dw_mfma", &CasyncOptions::ir_dw_mfma},
     {"ups_commute_bf16", &CasyncOptions::ups_commute_bf16},
     {"fuse_dw_bf16", &CasyncOptions::fuse_dw_bf16},
     {"fuse_dw_bf16_bn", &CasyncOptions::fuse_dw_bf16_bn},

@@ -33,8 +33,10 @@ MIN_WAVES = {
     "ir_fused_kernel<float, 64, 256, 32, 1, 16, 2>": 2,          # up3.0, upsample commuted
     "ir_fused_kernel<float, 64, 128, 64, 1, 16, 0>": 3,          # down1.1
     "ir_fused_kernel<float, 32, 64, 64, 2, 16, 0>": 3,           # down1.0
-    "ir_fused_bf16_kernel<64, 128, 32, 1, true>": 3,             # (round 4: D in registers, stacked pixels share tap rows)
-    "ir_fused_bf16_kernel<32, 64, 32, 1, false>": 4,
+    "ir_fused_bf16_kernel<64, 128, 32, 1, true, true>": 3,       # (round 6: depthwise on the matrix pipe)
+    "ir_fused_bf16_kernel<32, 64, 32, 1, false, true>": 4,
+    "ir_fused_bf16_kernel<64, 128, 32, 1, true, false>": 3,      # (round 4: D in registers, stacked pixels share tap rows)
+    "ir_fused_bf16_kernel<32, 64, 32, 1, false, false>": 4,
     "pw_dw_kernel<10, 2, 32, 16, 1, 2>": 5,                         # (LDS allows four workgroups per CU; round 4: 9 tap weights + 3 column offsets)
     "pw_dw_kernel<20, 1, 32, 16, 1, 2>": 5,
     "pw_dw_strip_kernel<40, 8, 1, 32, 16>": 4,                   # (57 KB of LDS: two workgroups per CU either way)
