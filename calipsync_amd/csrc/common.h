@@ -77,6 +77,8 @@ struct CasyncOptions {
   int gemm_streamk = 1;      // CASYNC_GEMM_STREAMK: K may be split (stream-K remainders, the small-M tile) in single-lane runs; 0 = batch-invariant bits
   int gemm_glds = 2;         // CASYNC_GEMM_GLDS: LDS-DMA ring GEMM: 0 off, 1 bf16 only, 2 both types
   int gemm_cfg = -1;         // CASYNC_GEMM_CFG: force one tile configuration
+  int gemm_ring128 = 0;      // CASYNC_GEMM_RING128: bf16 128x128 launches of more than 256 tiles on a two-stage LDS-DMA ring, two workgroups per CU
+                             //   (round-6 experiment; 0 = the register-staged 128x128 kernel)
   int gemm_single64 = 4096;  // CASYNC_GEMM_SINGLE64: single-lane fp32 launches of at most this many 64x64 tiles take 64x64 tiles only (0 = cost model)
   int skip_early = 12;       // CASYNC_SKIP_EARLY: below this many frames (single lane, fp32) the skip half of up1.0 / up2.0's expand conv runs
                              //   on the second stream beside the trunk and the decoder only adds up(W1a . lo) inside the depthwise kernel (0 = off)

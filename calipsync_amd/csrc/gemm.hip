@@ -363,7 +363,10 @@ __device__ __attribute__((aligned(256))) float g_zero_page[64];
 // waves per SIMD the register allocator must leave room for: the 64x64 two-stage ring needs 32 KB of LDS, so five
 // workgroups fit a CU -- if the kernel stays within 512 / 5 = 102 registers
 template <typename T, int BM, int BN, int NST, bool CONV>
-constexpr int glds_min_waves() { return sizeof(T) == 4 && BM == 64 && BN == 64 && NST == 2 && !CONV ? 5 : 1; }
+constexpr int glds_min_waves() {
+  if (sizeof(T) == 2 && BM == 128 && BN == 128 && NST == 2 && !CONV) return 2;   // round-6 experiment: two 64-KB rings per CU
+  return sizeof(T) == 4 && BM == 64 && BN == 64 && NST == 2 && !CONV ? 5 : 1;
+}
 
 template <typename T, int BM, int BN, int WM, int WN, int NST, bool CONV, bool EUPS>
 __device__ __forceinline__ void glds_body(const T* __restrict__ A, int lda, const T* __restrict__ W, T* __restrict__ C,
@@ -924,6 +927,14 @@ int launch_cfg(const void* a, int lda, const void* w, void* c, int ldc, int m, i
   const size_t esz = dtype == DT_BF16 ? 2 : 4;
   const bool fits32 = ((size_t)(m - 1) * lda + k) * esz < (1ull << 31) && (size_t)n * k * esz < (1ull << 31);
   const bool ring_ok = fits32 && ((BM + BN) < 256 || tiles <= 256);
+  if constexpr (BM == 128 && BN == 128) {
+    // round-6 experiment (`gemm_ring128`): the 128x128 bf16 tile on a TWO-stage ring, two workgroups per CU
+    // (64 KB each), for the multi-round launches the register-staged kernel serves -- the configuration missing from
+    // profiles/r5_bf16_gemm_variants.txt (the ring has no ds_write, which that table priced at 15-35 % of the staged kernel)
+    if (fits32 && dtype == DT_BF16 && glds_mode() >= 1 && casync_opts().gemm_ring128 && tiles > 256)
+      return launch_glds_t<bf16_t, 128, 128, WM, WN, 2>(static_cast<const bf16_t*>(a), lda, static_cast<const bf16_t*>(w),
+                                                        static_cast<bf16_t*>(c), ldc, m, n, k, epi, stream, use_sk);
+  }
   if constexpr (WM * WN == 4 && BN >= 64) {
     if (ring_ok && dtype == DT_BF16 && glds_mode() >= 1) {
       return launch_glds_t<bf16_t, BM, BN, WM, WN, NST2>(static_cast<const bf16_t*>(a), lda, static_cast<const bf16_t*>(w),
@@ -1039,7 +1050,11 @@ const char* pw_gemm_kernel_name(int m, int n, int k, bool stream_k, int dtype, b
   }
   const TileCfg& tc = kTiles[id];
   const long long tiles = (long long)((m + tc.bm - 1) / tc.bm) * (n / tc.bn);
-  if (takes_ring(tc, tiles, dtype))
+  const size_t esz = dtype_size(dtype);
+  if (id == C128x128 && dtype == DT_BF16 && glds_mode() >= 1 && casync_opts().gemm_ring128 && tiles > 256 &&
+      (size_t)m * k * esz < (1ull << 31) && (size_t)n * k * esz < (1ull << 31))
+    snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<__bf16, 128, 128, 2, 2, 2, false>");
+  else if (takes_ring(tc, tiles, dtype))
     snprintf(buf, sizeof(buf), "pw_gemm_glds_kernel<%s, %s, %d, false>", t, cfg, id == C64x32 ? 4 : (tc.bm + tc.bn >= 256 ? 3 : 2));
   else
     snprintf(buf, sizeof(buf), "pw_gemm_kernel<%s, %s>", t, cfg);

@@ -22,6 +22,7 @@ const OptField kFields[] = {
     {"gemm_streamk", &CasyncOptions::gemm_streamk},
     {"gemm_glds", &CasyncOptions::gemm_glds},
     {"gemm_cfg", &CasyncOptions::gemm_cfg},
+    {"gemm_ring128", &CasyncOptions::gemm_ring128},
     {"gemm_small_m", &CasyncOptions::gemm_small_m},
     {"skip_early", &CasyncOptions::skip_early},
     {"gemm_single64", &CasyncOptions::gemm_single64},

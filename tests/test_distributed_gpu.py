@@ -72,6 +72,26 @@ def test_bench_launches_its_own_ranks():
     assert c["broadcast_bytes"] == 4 * _lib.load().casync_packed_total() and c["broadcast_ms"] > 0 and c["collectives_per_step"] == 0
 
 
+def test_bench_rehearses_a_many_rank_launch():
+    """The launcher, the port choice, `shard_range`, the strong leg and the `config.rccl` block at the largest world size the
+    one-GPU box allows: FIVE ranks sharing the GPU over gloo (its process guard kills a run with more than six GPU processes,
+    and this pytest process is one; the driver's N = 8 run is the same code with RANK 0..7 -- `tests/test_sharding.py` covers
+    the 4096-over-8 split and `tests/test_bench_launcher.py` the N = 8 watchdog on the CPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "5", "--steps", "2", "--warmup", "1",
+                          "--batch", "8", "--strong-frames", "320", "--no-cpu-baseline"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 5 and r["config"]["world_size"] == 5 and r["config"]["global_batch"] == 40 and r["scaling"] == "weak"
+    c = r["config"]["rccl"]
+    assert c["world"] == 5 and c["backend"] == "gloo" and c["unique_devices"] == 1 and c["collectives_per_step"] == 0
+    s = r["config"]["strong_scaling"]
+    assert s["global_batch"] == 320 and s["frames_per_gpu"] == 64 and s["scaling"] == "strong" and s["n_gpus"] == 5 and s["value"] > 0
+
+
 _SHARD_WORKER = r"""
 import os, sys
 import torch

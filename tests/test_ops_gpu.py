@@ -698,3 +698,26 @@ def test_up_block_expand_with_commuted_upsample_bf16(bf16_ops, hw, c_lo, cexp, f
     top = float(ref.abs().max())
     err = (got - ref).abs()
     assert float(err.max()) / top < 2 ** -6 and float(err.mean()) / top < 2 ** -10
+
+
+@pytest.mark.parametrize("m,n,k", [(25600, 512, 256), (33001, 256, 512), (40000, 128, 1024)])
+def test_pw_gemm_bf16_two_stage_ring_128(bf16_ops, m, n, k):
+    """Round-6 experiment instance (`gemm_ring128`): the 128x128 bf16 tile on a two-stage LDS-DMA ring, launches of more than
+    256 tiles (ragged M included), against the register-staged kernel on the same operands: bit-identical (same products, same
+    k order) and within the bf16 rounding of an fp64 reference."""
+    lib = bf16_ops
+    g = torch.Generator().manual_seed(m + n)
+    a = torch.randn(m, k, generator=g).bfloat16()
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).bfloat16()
+    b = torch.randn(n, generator=g)
+    ad, wd, bd = a.to(dev()), w.to(dev()), b.to(dev())
+    outs = []
+    for ring in (0, 1):
+        c = torch.full((m, n), 9.0, device=dev(), dtype=torch.bfloat16)
+        with options(gemm_ring128=ring, gemm_cfg=0):
+            ok(lib.casync_op_pw_gemm(ptr(ad), k, ptr(wd), ptr(bd), ptr(c), n, m, n, k, 1, 0, 0, 0, 0, 0, 0, 0, stream()))
+        outs.append(c.cpu())
+    ref = F.leaky_relu(a[:4096].double() @ w.double().T + b.double(), 0.01)
+    err = (outs[1][:4096].double() - ref).abs() / (ref.abs() + 1.0)
+    assert float(err.max()) < 2 ** -8
+    assert torch.equal(outs[0], outs[1])

@@ -1,4 +1,4 @@
-"""Frame sharding + the one-time weight broadcast, world_size 2 over gloo on the CPU."""
+"""Frame sharding + the one-time weight broadcast, world_size 2 and 8 over gloo on the CPU."""
 import os
 import sys
 
@@ -25,7 +25,7 @@ def test_shard_range_partitions_exactly():
         shard_range(10, 2, 2)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n_frames=5):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -43,7 +43,7 @@ def _worker(rank, world, port, q):
                               dtype=torch.float64)
         gathered = [torch.zeros_like(digest) for _ in range(world)]
         dist.all_gather(gathered, digest)
-        x = torch.arange(5 * 6, dtype=torch.float32).reshape(5, 6)
+        x = torch.arange(n_frames * 6, dtype=torch.float32).reshape(n_frames, 6)
         xs, _ = shard_frames(x, x, rank, world)
         q.put((rank, [g.tolist() for g in gathered], xs[:, 0].tolist(), bool((buf != 0).any())))
     finally:
@@ -65,6 +65,29 @@ def test_weight_broadcast_and_frame_shards_world2():
     assert g0 == g1 and g0[0] == g0[1]          # identical buffers on both ranks
     assert nz0 and nz1
     assert f0 == [0.0, 6.0, 12.0] and f1 == [18.0, 24.0]   # 5 frames -> 3 + 2, contiguous
+
+
+def test_weight_broadcast_and_frame_shards_world8():
+    """The world size of BASELINE configs[3] (one process per GPU of an 8-GPU node), rehearsed over gloo on the CPU: ONE
+    broadcast leaves rank 0's folded weights on all eight ranks, and the 4096-frame job is cut into eight contiguous
+    512-frame shards (here: 11 frames -> 2 2 2 1 1 1 1 1, contiguous, in rank order)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, q, 11)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=480) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    digests = [g for _, g, _, _ in res]
+    assert all(d == digests[0] for d in digests) and all(row == digests[0][0] for row in digests[0])   # eight identical buffers
+    assert all(nz for _, _, _, nz in res)
+    frames = [f for _, _, f, _ in res]
+    assert [len(f) for f in frames] == [2, 2, 2, 1, 1, 1, 1, 1]
+    assert sum(frames, []) == [6.0 * i for i in range(11)]
+    assert [shard_range(4096, r, 8) for r in range(8)] == [(512 * r, 512) for r in range(8)]
 
 
 def test_forward_chunked_walks_a_shard_in_order():
