@@ -494,6 +494,9 @@ def main():
     # ---- per-kernel timing with HIP events on the launch stream (rank 0)
     result = None
     lanes = net.get_option("lanes")
+    plan16 = net.get_option("bf16_plan")
+    if args.dtype == "bf16" and plan16 > 0 and B >= plan16 and lanes == 2:
+        lanes = 3                   # the bf16 engine's large-batch plan (engine.hip run_forward): three lanes, gemm_ring128, overlap 0
     trunk_lanes = net.get_option("trunk_lanes")
     if rank == 0:
         per = {}

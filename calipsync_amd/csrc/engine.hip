@@ -307,6 +307,7 @@ struct casync_engine {
   hipEvent_t ev_start = nullptr, ev_start2 = nullptr;
   bool streams_ready = false;
   CasyncOptions opt;         // this handle's switches: process defaults at create, casync_set_option afterwards
+  CasyncOptions eff;         // what the forward in progress runs under (run_forward: `opt` + the bf16 large-batch plan)
   const float* W(const std::string& name) const { return w + layout().off(name); }
   // GEMM weight matrix in the engine's storage type
   const void* WG(const std::string& name) const {
@@ -405,7 +406,7 @@ struct Plan {
   const float* win_feat = nullptr;
   int win_steps = 0;
   const int* win_idx = nullptr;
-  const CasyncOptions& o = e.opt;
+  const CasyncOptions& o = e.eff;     // the options of the forward in progress (run_forward)
 
   // GEMM wrapper with work accounting (algorithmic bytes: A + C once, W once)
   int dt() const { return e.dtype; }
@@ -998,8 +999,17 @@ struct FwdArgs {
 // no host sync.  prof != null: the SAME launches (same lanes, sub-batches, kernels, grids) serialised
 // on the caller's stream with an event pair around each; synchronises.
 static int run_forward(casync_handle h, const FwdArgs& A, hipStream_t caller, std::vector<casync_kernel_time>* prof) {
-  const CasyncOptions& o = h->opt;
-  CasyncOptScope scope(&h->opt);
+  // the options this forward runs under: the handle's, plus -- bf16 engine, from `bf16_plan` frames -- the large-batch plan
+  // measured in round 6 (profiles/r6_ab_bf16_plan.txt: B = 512 43.65 -> 45.94 k frames/s, B = 128 +0.8 %): three lanes, the
+  // 128x128 GEMM tile on the two-stage ring, the audio encoder on its lane's own stream
+  h->eff = h->opt;
+  if (h->dtype == DT_BF16 && h->opt.bf16_plan > 0 && A.batch >= h->opt.bf16_plan) {
+    h->eff.lanes = h->opt.lanes == 2 ? 3 : h->opt.lanes;     // (a caller who set another lane count keeps it)
+    h->eff.gemm_ring128 = 1;
+    h->eff.overlap = 0;
+  }
+  const CasyncOptions& o = h->eff;
+  CasyncOptScope scope(&h->eff);
   DeviceGuard guard(h->device);
   CASYNC_CHECK_HIP(guard.err);
   const bool serial = prof != nullptr;

@@ -41,6 +41,7 @@ const OptField kFields[] = {
     {"fuse_dw_deep", &CasyncOptions::fuse_dw_deep},
     {"att_bf16", &CasyncOptions::att_bf16},
     {"ir_dw_mfma", &CasyncOptions::ir_dw_mfma},
+    {"bf16_plan", &CasyncOptions::bf16_plan},
     {"ups_commute_bf16", &CasyncOptions::ups_commute_bf16},
     {"fuse_dw_bf16", &CasyncOptions::fuse_dw_bf16},
     {"fuse_dw_bf16_bn", &CasyncOptions::fuse_dw_bf16_bn},
