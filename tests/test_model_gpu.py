@@ -281,7 +281,9 @@ def test_bf16_engine_error_is_reported_not_hidden(net_bf16, golden):
 # measured max relative error per tap + 25 % (round 2; u4 re-measured in round 5: the attention core on bf16 matrix
 # instructions rounds P to bf16 -- the MAX over u4 moved 9.7e-3 -> 1.11e-2 while `fuse` moved 8.4e-3 -> 6.5e-3, the B=512
 # maximum 9.5e-3 -> 8.9e-3 and every MEAN stayed where it was (1.04e-3 on the output): extreme values of rounding noise)
-BF16_TAP_BARS = {"x1": 3.0e-3, "x5": 8.0e-3, "a": 9.6e-3, "tx": 5.5e-3, "kx": 9.8e-3, "fuse": 9.4e-3, "u4": 1.4e-2}
+# (round 6, depthwise taps of the fused blocks as bf16 on the matrix pipe, `ir_dw_mfma`: the MAX over `tx` -- behind the audio encoder's two
+# fused blocks -- moved 4.4e-3 -> 6.5e-3 while u4's moved 1.11e-2 -> 7.95e-3; output max 8.49e-3 -> 8.48e-3, mean 1.04e-3 -> 1.00e-3)
+BF16_TAP_BARS = {"x1": 3.0e-3, "x5": 8.0e-3, "a": 9.6e-3, "tx": 8.1e-3, "kx": 9.8e-3, "fuse": 9.4e-3, "u4": 1.4e-2}
 
 
 @pytest.mark.parametrize("name", sorted(BF16_TAP_BARS))
