@@ -279,9 +279,12 @@ class VideoStreamManager:
             try:
                 from . import mjpeg_avi
                 out = os.path.splitext(output_path)[0] + ".avi"
+                print(f"VideoStreamManager: no OpenCV / ffmpeg here -- writing {out} (Motion-JPEG AVI, {self.fps} fps, NO audio track) "
+                      f"instead of {output_path}")
                 mjpeg_avi.write_mjpeg_avi(out, frames, fps=self.fps)
                 return out
-            except ImportError:
+            except (ImportError, ValueError) as exc:      # no Pillow, or a clip past the 4 GiB AVI limit: the raw frames
+                print(f"VideoStreamManager: {exc}; writing the raw frames to {output_path}.npy")
                 np.save(output_path + ".npy", np.stack(frames))
                 return output_path + ".npy"
         height, width = frames[0].shape[:2]

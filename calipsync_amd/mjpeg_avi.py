@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import io
 import struct
-from typing import Iterable, List
+from typing import Iterable
 
 import numpy as np
 
@@ -34,37 +34,70 @@ def encode_jpeg(frame_bgr: np.ndarray, quality: int = 95) -> bytes:
     return buf.getvalue()
 
 
+RIFF_LIMIT = (1 << 32) - (1 << 20)     # 32-bit RIFF sizes (plain AVI, no OpenDML segments): stop a MiB short of 4 GiB
+
+
 def write_mjpeg_avi(path: str, frames: Iterable[np.ndarray], fps: float = 25.0, quality: int = 95) -> int:
-    """Write `frames` (BGR uint8, all the same size) to `path` as Motion-JPEG AVI; returns the frame count."""
-    jpegs: List[bytes] = []
-    width = height = None
-    for f in frames:
-        if width is None:
-            height, width = f.shape[:2]
-        elif f.shape[:2] != (height, width):
-            raise ValueError("all frames of a video must have the same size")
-        jpegs.append(encode_jpeg(f, quality))
-    if not jpegs:
-        raise ValueError("no video frame was generated")
-    n = len(jpegs)
-    biggest = max(len(j) for j in jpegs)
+    """Write `frames` (BGR uint8, all the same size) to `path` as Motion-JPEG AVI; returns the frame count.
+
+    Frames are encoded and written one at a time (one JPEG in memory, not the clip); the header fields that depend on
+    the whole clip (frame count, largest chunk, RIFF / LIST sizes) are patched when the last frame is on disk.  The
+    container is plain RIFF/AVI with 32-bit sizes: a clip that would pass 4 GiB (about five minutes of 1080p at this
+    quality) raises ValueError at the frame that would cross the limit, and the partial file is removed -- it fails while
+    encoding, not after it."""
     usec = int(round(1e6 / fps))
     rate, scale = int(round(fps * 1000)), 1000
-    avih = struct.pack("<14I", usec, int(biggest * fps), 0, 0x10, n, 0, 1, biggest, width, height, 0, 0, 0, 0)   # 0x10 = AVIF_HASINDEX
-    strh = b"vids" + b"MJPG" + struct.pack("<IHHIIIIIIII4H", 0, 0, 0, 0, scale, rate, 0, n, biggest, 0xFFFFFFFF, 0, 0, 0, width, height)
-    strf = struct.pack("<IiiHH4sIiiII", 40, width, height, 1, 24, b"MJPG", width * height * 3, 0, 0, 0, 0)
-    hdrl = _list(b"hdrl", _chunk(b"avih", avih) + _list(b"strl", _chunk(b"strh", strh) + _chunk(b"strf", strf)))
-    movi_body, index, off = b"", b"", 4                      # idx1 offsets count from the 'movi' fourcc
-    parts = []
-    for j in jpegs:
-        parts.append(_chunk(b"00dc", j))
-        index += b"00dc" + struct.pack("<III", 0x10, off, len(j))   # 0x10 = AVIIF_KEYFRAME
-        off += len(parts[-1])
-    movi_body = b"".join(parts)
-    riff_body = b"AVI " + hdrl + _list(b"movi", movi_body) + _chunk(b"idx1", index)
-    with open(path, "wb") as fh:
-        fh.write(b"RIFF" + struct.pack("<I", len(riff_body)) + riff_body)
-    return n
+    n, biggest, width, height = 0, 0, None, None
+    index = []
+    fh = None
+    try:
+        for f in frames:
+            if width is None:
+                height, width = f.shape[:2]
+                fh = open(path, "wb")
+                # header with the clip-dependent fields zeroed: patched below (positions recorded as they are written)
+                avih = struct.pack("<14I", usec, 0, 0, 0x10, 0, 0, 1, 0, width, height, 0, 0, 0, 0)   # 0x10 = AVIF_HASINDEX
+                strh = b"vids" + b"MJPG" + struct.pack("<IHHIIIIIIII4H", 0, 0, 0, 0, scale, rate, 0, 0, 0, 0xFFFFFFFF, 0, 0, 0, width, height)
+                strf = struct.pack("<IiiHH4sIiiII", 40, width, height, 1, 24, b"MJPG", width * height * 3, 0, 0, 0, 0)
+                hdrl = _list(b"hdrl", _chunk(b"avih", avih) + _list(b"strl", _chunk(b"strh", strh) + _chunk(b"strf", strf)))
+                fh.write(b"RIFF" + struct.pack("<I", 0) + b"AVI " + hdrl)
+                movi_at = fh.tell()
+                fh.write(b"LIST" + struct.pack("<I", 0) + b"movi")
+                off = 4                                              # idx1 offsets count from the 'movi' fourcc
+            elif f.shape[:2] != (height, width):
+                raise ValueError("all frames of a video must have the same size")
+            j = encode_jpeg(f, quality)
+            chunk = _chunk(b"00dc", j)
+            if fh.tell() + len(chunk) + 16 * (n + 1) + 8 > RIFF_LIMIT:
+                raise ValueError(f"{path}: the clip passes the 4 GiB limit of a plain AVI file at frame {n} "
+                                 f"({fh.tell() / 2 ** 30:.2f} GiB written): write it in shorter segments")
+            fh.write(chunk)
+            index.append((off, len(j)))
+            off += len(chunk)
+            biggest = max(biggest, len(j))
+            n += 1
+        if n == 0:
+            raise ValueError("no video frame was generated")
+        movi_size = fh.tell() - movi_at - 8
+        fh.write(_chunk(b"idx1", b"".join(b"00dc" + struct.pack("<III", 0x10, o, ln) for o, ln in index)))   # 0x10 = AVIIF_KEYFRAME
+        riff_size = fh.tell() - 8
+        # patches: RIFF size; avih (at 32): dwMaxBytesPerSec (+4), dwTotalFrames (+16), dwSuggestedBufferSize (+28);
+        # strh (at 108): dwLength (+32), dwSuggestedBufferSize (+36); the movi LIST size
+        for pos, value in ((4, riff_size), (32 + 4, int(biggest * fps)), (32 + 16, n), (32 + 28, biggest),
+                           (108 + 32, n), (108 + 36, biggest), (movi_at + 4, movi_size)):
+            fh.seek(pos)
+            fh.write(struct.pack("<I", value))
+        fh.close()
+        fh = None
+        return n
+    finally:
+        if fh is not None:              # an error part-way: no half-written file is left behind
+            fh.close()
+            try:
+                import os
+                os.remove(path)
+            except OSError:
+                pass
 
 
 def read_mjpeg_avi(path: str):

@@ -40,3 +40,28 @@ def test_mjpeg_avi_rejects_bad_input(tmp_path):
         mjpeg_avi.write_mjpeg_avi(str(tmp_path / "m.avi"), [_frames(1)[0], _frames(1, h=64)[0]])
     with pytest.raises(ValueError):
         mjpeg_avi.encode_jpeg(np.zeros((8, 8), np.uint8))
+
+
+def test_mjpeg_avi_streams_and_fails_early_at_the_size_limit(tmp_path, monkeypatch):
+    """frames are written as they are encoded (a generator is enough), the clip-dependent header fields are patched
+    at the end, and a clip that would pass the 32-bit RIFF limit fails at THAT frame -- not after encoding everything -- and
+    leaves no partial file behind."""
+    path = str(tmp_path / "gen.avi")
+    assert mjpeg_avi.write_mjpeg_avi(path, (f for f in _frames(5)), fps=25) == 5           # a generator: nothing is kept
+    raw = open(path, "rb").read()
+    total, largest = struct.unpack("<I", raw[48:52])[0], struct.unpack("<I", raw[60:64])[0]   # avih.dwTotalFrames, dwSuggestedBufferSize
+    assert total == 5 and 0 < largest < len(raw)
+    assert mjpeg_avi.read_mjpeg_avi(path)[0] == 25.0 and len(mjpeg_avi.read_mjpeg_avi(path)[1]) == 5
+    seen = []
+
+    def frames():
+        for i, f in enumerate(_frames(50)):
+            seen.append(i)
+            yield f
+
+    monkeypatch.setattr(mjpeg_avi, "RIFF_LIMIT", len(raw))                                  # room for about five frames
+    big = str(tmp_path / "big.avi")
+    with pytest.raises(ValueError, match="4 GiB"):
+        mjpeg_avi.write_mjpeg_avi(big, frames(), fps=25)
+    assert len(seen) < 10 and not os.path.exists(big)                                       # stopped at the limit, cleaned up
+    assert not os.path.exists(str(tmp_path / "e.avi"))
