@@ -111,6 +111,8 @@ struct CasyncOptions {
   int ir_dw_mfma = 1;        // CASYNC_IR_DW_MFMA: the bf16 fused inverted-residual block runs its depthwise 3x3 on the matrix pipe (block-diagonal
                              //   v_mfma_f32_16x16x32_bf16, taps rounded to bf16): 1 = in the instances where that measured faster (all but
                              //   up4.0's 64 -> 128 -> 32), 2 = in all, 0 = the VALU form with fp32 taps (round 5)
+  int inc_mfma = 0;          // CASYNC_INC_MFMA: the bf16 engine's `inc` block projects 12 -> 32 channels on the matrix pipe (inc_bf16_kernel: the kernel
+                             //   0.49 -> 0.37 ms per B = 512 step, end to end +0.5 %, the x1 tap's max error 2.4e-3 -> 3.7e-3: off by default)
   int bf16_plan = 256;       // CASYNC_BF16_PLAN: frames per forward from which the bf16 engine runs its large-batch plan -- three lanes (when `lanes`
                              //   is at its default 2), `gemm_ring128`, the audio encoder on the lane's own stream (`overlap` 0); 0 = never
   int dw_lds = 1;            // CASYNC_DW_LDS: LDS-slab depthwise kernel

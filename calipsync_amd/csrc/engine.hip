@@ -593,7 +593,7 @@ struct Plan {
       r.s = main_s;
     }
     // ---------------- face encoder (module/unet.py:315-319)
-    r.run("inc", kname("inc_kernel").c_str(), 2.0 * B * 25600 * (72 + 108 + 384),
+    r.run("inc", dt() == DT_BF16 && o.inc_mfma ? "inc_bf16_kernel" : kname("inc_kernel").c_str(), 2.0 * B * 25600 * (72 + 108 + 384),
           (double)B * 25600 * (6 * 4 + 32 * dtype_size(dt())), [&] {
       return launch_inc(x, e.W("inc.inconv.0.fused"), ar[A::CAT4] + 32, 64, B, r.s, dt());
     });

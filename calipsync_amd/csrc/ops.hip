@@ -452,6 +452,113 @@ __global__ __launch_bounds__(256) void inc_kernel(const float* __restrict__ x,
   }
 }
 
+// inc for the bf16 engine (round 6): the 12 -> 32 projection is two thirds of the block's multiply-adds (384 of 564 per pixel)
+// and dense, so it runs on v_mfma_f32_16x16x32_bf16 (K = 12 of 32) instead of 192 packed fp32 FMAs per pixel.  Phases A / B
+// (expand over the halo, depthwise 3x3) are inc_kernel's, in fp32.  Then a thread's twelve depthwise outputs go to LDS as
+// bf16 (64 B per pixel: high and low halves of 12 channels, see below) -- read back by the same wave as the MFMA B operand (lane (q, n) = K-slots
+// 8 q .. 8 q + 7 of pixel n: one 16-byte read), no workgroup barrier: LDS operations of a wave are in
+// order -- W2's rows enter as the A operand permuted (row r of tile t = output channel 8 (r >> 2) + 4 t + (r & 3)) so that a
+// lane's rows 4 q .. 4 q + 3 of both tiles are the eight consecutive channels 8 q .. 8 q + 7 of its pixel: bias is the
+// accumulators' initial value, LeakyReLU + narrowing run on 8 values per lane and 16 pixels, and every pixel's 64-byte NHWC
+// row leaves as four 16-byte stores of one instruction.  No staging of the output through LDS (inc_kernel: 34 KB), so six
+// instead of three workgroups fit a CU.  W2 is rounded to bf16 before the product (fp32 accumulate), as in every other GEMM of
+// the bf16 engine; the depthwise output enters as a bf16 high + low pair.
+__global__ __launch_bounds__(256) void inc_bf16_kernel(const float* __restrict__ x, const float* __restrict__ packed,
+                                                       bf16_t* __restrict__ out, int ldc, int nwg) {
+  __shared__ f32x2 E[INC_CEXP / 2][INC_HALO + 2];
+  __shared__ __attribute__((aligned(16))) bf16_t Dl[256][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+  const f32x2* w1 = reinterpret_cast<const f32x2*>(packed);          // [6 ci][6 pairs of ce]
+  const f32x2* b1 = reinterpret_cast<const f32x2*>(packed + 72);
+  const f32x2* wd = reinterpret_cast<const f32x2*>(packed + 84);     // [9 taps][6 pairs]
+  const f32x2* bd = reinterpret_cast<const f32x2*>(packed + 192);
+  const float* w2 = packed + 204;                                    // [12 ce][32 co]
+  const float* b2 = packed + 588;
+  // the two weight fragments (A operand) and the bias rows of this lane: once per workgroup, from L2
+  bf16x8 fw[2];
+  f32x4 bias[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int oc = 8 * (l15 >> 2) + 4 * t + (l15 & 3);
+    float w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {   // (every lane loads from a valid row, the K-slots past channel 11 are zeroed afterwards: no divergent code)
+      const int ce = (8 * q + j) & 15;                    // K-slots 16 .. 27 repeat 0 .. 11: they meet the LOW halves of D
+      const float v = w2[(ce < INC_CEXP ? ce : INC_CEXP - 1) * INC_COUT + oc];
+      w[j] = ce < INC_CEXP ? v : 0.f;
+    }
+    const bf16x4 lo = __builtin_convertvector(f32x4{w[0], w[1], w[2], w[3]}, bf16x4), hi = __builtin_convertvector(f32x4{w[4], w[5], w[6], w[7]}, bf16x4);
+    fw[t] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    bias[t] = *reinterpret_cast<const f32x4*>(b2 + 8 * q + 4 * t);
+  }
+  const int bid = xcd_run(blockIdx.x, nwg);
+  const int b = bid / INC_TILES, t = bid - b * INC_TILES;
+  const int ty0 = (t / INC_TX) * INC_TH, tx0 = (t % INC_TX) * INC_TW;
+  const float* xb = x + (size_t)b * INC_CIN * INC_HW * INC_HW;
+  for (int p = tid; p < INC_HALO; p += 256) {
+    const int hy = p / INC_HALO_W, hx = p - hy * INC_HALO_W;
+    const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+    const bool inside = iy >= 0 && iy < INC_HW && ix >= 0 && ix < INC_HW;
+    float v[INC_CIN];
+#pragma unroll
+    for (int ci = 0; ci < INC_CIN; ++ci)
+      v[ci] = inside ? xb[((size_t)ci * INC_HW + iy) * INC_HW + ix] : 0.f;
+#pragma unroll
+    for (int cp = 0; cp < INC_CEXP / 2; ++cp) {
+      f32x2 s2 = b1[cp];
+#pragma unroll
+      for (int ci = 0; ci < INC_CIN; ++ci) s2 = __builtin_elementwise_fma(w1[ci * (INC_CEXP / 2) + cp], f32x2{v[ci], v[ci]}, s2);
+      E[cp][p] = inside ? lrelu2(s2) : f32x2{0.f, 0.f};
+    }
+  }
+  __syncthreads();
+  const int ly = tid >> 5, lx = tid & 31;
+  f32x2 d[INC_CEXP / 2];
+#pragma unroll
+  for (int cp = 0; cp < INC_CEXP / 2; ++cp) {
+    f32x2 s2 = bd[cp];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+        s2 = __builtin_elementwise_fma(wd[(ky * 3 + kx) * (INC_CEXP / 2) + cp], E[cp][(ly + ky) * INC_HALO_W + lx + kx], s2);
+    d[cp] = lrelu2(s2);
+  }
+  {
+    // D as bf16 HIGH + LOW halves (d = hi + lo to 16 mantissa bits): the K = 32 of the MFMA has room for both (slots 0 .. 11
+    // and 16 .. 27 against the same weights), so the depthwise output enters the product almost unrounded at no extra
+    // matrix instruction -- only W2 is rounded to bf16 (with hi alone the x1 tap's max error was 6.2e-3 against 2.4e-3)
+    const f32x4 da = {d[0].x, d[0].y, d[1].x, d[1].y}, db = {d[2].x, d[2].y, d[3].x, d[3].y}, dc = {d[4].x, d[4].y, d[5].x, d[5].y};
+    const bf16x4 h0 = __builtin_convertvector(da, bf16x4), h1 = __builtin_convertvector(db, bf16x4), h2 = __builtin_convertvector(dc, bf16x4);
+    const bf16x4 l0 = __builtin_convertvector(da - __builtin_convertvector(h0, f32x4), bf16x4);
+    const bf16x4 l1 = __builtin_convertvector(db - __builtin_convertvector(h1, f32x4), bf16x4);
+    const bf16x4 l2 = __builtin_convertvector(dc - __builtin_convertvector(h2, f32x4), bf16x4);
+    const bf16_t z = (bf16_t)0.f;
+    *reinterpret_cast<bf16x8*>(&Dl[tid][0]) = bf16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    *reinterpret_cast<bf16x8*>(&Dl[tid][8]) = bf16x8{h2[0], h2[1], h2[2], h2[3], z, z, z, z};
+    *reinterpret_cast<bf16x8*>(&Dl[tid][16]) = bf16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    *reinterpret_cast<bf16x8*>(&Dl[tid][24]) = bf16x8{l2[0], l2[1], l2[2], l2[3], z, z, z, z};
+  }
+  // (same wave wrote what it reads: no barrier; the compiler's lgkmcnt wait orders the read behind the writes)
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * INC_HW * INC_HW * ldc, 0,
+                                                                           (unsigned)INC_HW * INC_HW * (unsigned)ldc * 2u, 0x00020000);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int p = 64 * wave + 16 * g + l15;                 // this lane's pixel of group g (the tile's pixel index = its thread)
+    const bf16x8 fb = *reinterpret_cast<const bf16x8*>(&Dl[p][8 * q]);
+    const f32x4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0], fb, bias[0], 0, 0, 0);
+    const f32x4 a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1], fb, bias[1], 0, 0, 0);
+    const f32x4 s0 = a0 * CASYNC_LRELU_SLOPE, s1 = a1 * CASYNC_LRELU_SLOPE;
+    const f32x4 v0 = {fmaxf(a0.x, s0.x), fmaxf(a0.y, s0.y), fmaxf(a0.z, s0.z), fmaxf(a0.w, s0.w)};
+    const f32x4 v1 = {fmaxf(a1.x, s1.x), fmaxf(a1.y, s1.y), fmaxf(a1.z, s1.z), fmaxf(a1.w, s1.w)};
+    const bf16x4 h0 = __builtin_convertvector(v0, bf16x4), h1 = __builtin_convertvector(v1, bf16x4);
+    const bf16x8 o = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    const int py = p >> 5, px = p & 31;
+    const unsigned off = (unsigned)((((ty0 + py) * INC_HW + tx0 + px) * ldc + 8 * q) * 2);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, 0, 0);
+  }
+}
+
 // ---------------------------------------------------------------- outc (32 -> 3, sigmoid)
 template <typename T>
 __global__ __launch_bounds__(256) void outc_kernel(const T* __restrict__ in, int ld_in,
@@ -662,6 +769,13 @@ int launch_inc(const float* x_nchw, const float* packed_inc, void* out, int ldc,
   CASYNC_REQUIRE(batch <= (1 << 20), "inc: batch %d", batch);
   CASYNC_REQUIRE(((uintptr_t)packed_inc % 8) == 0, "inc: the packed weights must be 8-B aligned");
   const int nwg = batch * INC_TILES;
+  if (dtype == DT_BF16 && casync_opts().inc_mfma) {
+    CASYNC_REQUIRE(ldc % 8 == 0 && ((uintptr_t)out % 16) == 0 && (long long)INC_HW * INC_HW * ldc * 2 < (1ll << 31),
+                   "inc (bf16): the output rows must be 16-B aligned and a frame smaller than 2 GiB");
+    hipLaunchKernelGGL(inc_bf16_kernel, dim3(nwg), dim3(256), 0, stream, x_nchw, packed_inc, (bf16_t*)out, ldc, nwg);
+    CASYNC_CHECK_HIP(hipGetLastError());
+    return CASYNC_OK;
+  }
   DT_DISPATCH(dtype,
               hipLaunchKernelGGL(inc_kernel<float>, dim3(nwg), dim3(256), 0, stream, x_nchw, packed_inc, (float*)out, ldc, nwg),
               hipLaunchKernelGGL(inc_kernel<bf16_t>, dim3(nwg), dim3(256), 0, stream, x_nchw, packed_inc, (bf16_t*)out, ldc, nwg));

@@ -42,6 +42,7 @@ const OptField kFields[] = {
     {"att_bf16", &CasyncOptions::att_bf16},
     {"ir_dw_mfma", &CasyncOptions::ir_dw_mfma},
     {"bf16_plan", &CasyncOptions::bf16_plan},
+    {"inc_mfma", &CasyncOptions::inc_mfma},
     {"ups_commute_bf16", &CasyncOptions::ups_commute_bf16},
     {"fuse_dw_bf16", &CasyncOptions::fuse_dw_bf16},
     {"fuse_dw_bf16_bn", &CasyncOptions::fuse_dw_bf16_bn},

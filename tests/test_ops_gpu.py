@@ -721,3 +721,28 @@ def test_pw_gemm_bf16_two_stage_ring_128(bf16_ops, m, n, k):
     err = (outs[1][:4096].double() - ref).abs() / (ref.abs() + 1.0)
     assert float(err.max()) < 2 ** -8
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("mfma", [1, 0])
+def test_inc_block_bf16(bf16_ops, recipe_sd, mfma):
+    """`inc` of the bf16 engine from the NCHW fp32 crop vs the oracle's module: the projection on the matrix pipe
+    (`inc_mfma`, round 6: depthwise output and W2 rounded to bf16 before the product) and the round-5 VALU kernel; a padded
+    leading dimension, nothing written outside the slice."""
+    from calipsync_amd import recipe
+    from oracle import unet_oracle
+    lib = bf16_ops
+    sd = unet_oracle.to_torch(recipe_sd)
+    x, _ = recipe.make_inputs(3)
+    xt = torch.from_numpy(x)
+    ref = unet_oracle.inverted_residual(sd, "inc.inconv.0", xt, 1, False)
+    packed = torch.from_numpy(pack.fold(recipe_sd)["inc.inconv.0.fused"].astype(np.float32)).to(dev())
+    out = torch.full((3, 160, 160, 64), 9.0, device=dev(), dtype=torch.bfloat16)
+    xd = xt.to(dev())
+    with options(inc_mfma=mfma):
+        ok(lib.casync_op_inc(ptr(xd), ptr(packed), out.data_ptr() + 32 * 2, 64, 3, stream()))
+    o = out.float().cpu()
+    assert (o[..., :32] == 9).all()
+    got = o[..., 32:].permute(0, 3, 1, 2)
+    err, mean = rel_err(got, ref), float((got - ref).abs().mean() / ref.abs().max())
+    print(f"inc bf16 mfma={mfma}: max rel {err:.3e} mean rel {mean:.3e}")
+    assert err < (6e-3 if mfma else 4e-3) and mean < 6e-4
