@@ -902,8 +902,8 @@ void casync_destroy(casync_handle h) {
   DeviceGuard guard(h->device);
   if (h->streams_ready) {
     for (int l = 0; l < casync_engine::kMaxLanes; ++l) {
-      if (h->lane_s[l]) { (void)hipStreamSynchronize(h->lane_s[l]); (void)hipStreamDestroy(h->lane_s[l]); }
-      if (h->aux[l]) { (void)hipStreamSynchronize(h->aux[l]); (void)hipStreamDestroy(h->aux[l]); }
+      if (h->lane_s[l]) (void)hipStreamSynchronize(h->lane_s[l]);   // (the streams belong to the process-wide pool: drained, not destroyed)
+      if (h->aux[l]) (void)hipStreamSynchronize(h->aux[l]);
       if (h->ev_fork[l]) (void)hipEventDestroy(h->ev_fork[l]);
       if (h->ev_join[l]) (void)hipEventDestroy(h->ev_join[l]);
       if (h->ev_done[l]) (void)hipEventDestroy(h->ev_done[l]);
@@ -960,19 +960,51 @@ int casync_load_weights_device(casync_handle h, const float* packed_dev, int64_t
   return refresh_bf16_weights(h, n_floats);
 }
 
-static int ensure_streams(casync_handle h) {   // caller holds a DeviceGuard for h->device
-  if (h->streams_ready) return CASYNC_OK;
-  CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
-  CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_start2, hipEventDisableTiming));
-  for (int l = 0; l < casync_engine::kMaxLanes; ++l) {
-    if (l) CASYNC_CHECK_HIP(hipStreamCreateWithFlags(&h->lane_s[l], hipStreamNonBlocking));
-    CASYNC_CHECK_HIP(hipStreamCreateWithFlags(&h->aux[l], hipStreamNonBlocking));
-    CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork[l], hipEventDisableTiming));
-    CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming));
-    CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_done[l], hipEventDisableTiming));
-    CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_mid[l], hipEventDisableTiming));
+// The engine's own streams are PROCESS-WIDE, one set per device, created as they are first needed (lane streams before
+// audio streams), and every handle borrows them.  Round 6: with a set per handle a second model in the process ran 7 %
+// slower than the first (bf16 B = 512: 45.7 k against 42.8 k frames/s, tools/experiments/bf16_after_fp32.py) -- the runtime
+// multiplexes a process's streams onto a few hardware queues, so the second model's lanes landed on queues that already
+// carried the first model's and serialised behind each other; `bench.py`'s bf16 leg inside the fp32 run read 42 k for the
+// same reason.  Streams only order work: two handles that share them stay correct (every forward orders itself with its
+// handle's own events), two forwards running at the same time share the queues -- as they did before.
+namespace {
+struct StreamPool {
+  std::mutex m;
+  hipStream_t lane[casync_engine::kMaxLanes] = {};   // [0] unused (caller's stream)
+  hipStream_t aux[casync_engine::kMaxLanes] = {};
+};
+StreamPool& stream_pool(int device) {
+  static StreamPool pools[64];
+  return pools[device < 0 || device >= 64 ? 0 : device];
+}
+}  // namespace
+
+static int ensure_streams(casync_handle h, int lanes, bool need_aux) {   // caller holds a DeviceGuard for h->device
+  if (!h->streams_ready) {
+    CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
+    CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_start2, hipEventDisableTiming));
+    for (int l = 0; l < casync_engine::kMaxLanes; ++l) {
+      CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork[l], hipEventDisableTiming));
+      CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming));
+      CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_done[l], hipEventDisableTiming));
+      CASYNC_CHECK_HIP(hipEventCreateWithFlags(&h->ev_mid[l], hipEventDisableTiming));
+    }
+    h->streams_ready = true;
   }
-  h->streams_ready = true;
+  bool missing = false;
+  for (int l = 0; l < lanes; ++l) missing |= (l && !h->lane_s[l]) || (need_aux && !h->aux[l]);
+  if (!missing) return CASYNC_OK;
+  StreamPool& pool = stream_pool(h->device);
+  std::lock_guard<std::mutex> lock(pool.m);
+  for (int l = 1; l < lanes; ++l) {
+    if (!pool.lane[l]) CASYNC_CHECK_HIP(hipStreamCreateWithFlags(&pool.lane[l], hipStreamNonBlocking));
+    h->lane_s[l] = pool.lane[l];
+  }
+  if (need_aux)
+    for (int l = 0; l < lanes; ++l) {
+      if (!pool.aux[l]) CASYNC_CHECK_HIP(hipStreamCreateWithFlags(&pool.aux[l], hipStreamNonBlocking));
+      h->aux[l] = pool.aux[l];
+    }
   return CASYNC_OK;
 }
 
@@ -1018,7 +1050,7 @@ static int run_forward(casync_handle h, const FwdArgs& A, hipStream_t caller, st
   if (A.batch < kMinLaneBatch * lanes) lanes = 1;  // small batches are latency-bound: cutting them only adds launches
   const bool hybrid = lanes > 1 && o.trunk_lanes == 1;
   if (overlap || lanes > 1) {
-    const int st = ensure_streams(h);
+    const int st = ensure_streams(h, lanes, overlap);
     if (st != CASYNC_OK) return st;
   }
   const int esz = dtype_size(h->dtype);
