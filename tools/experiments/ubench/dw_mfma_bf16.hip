@@ -300,10 +300,10 @@ int main() {
       if (rep > 0 && ms < best) best = ms;
     }
     if (mode == 0) base_ms = best;
-    const double chunks_per_simd = (double)nwg / 256 * 128;   // 4 waves per workgroup over 4 SIMDs: one wave-chunk per SIMD and chunk
-    printf("%-30s %.3f ms  %.0f ns per workgroup-chunk per CU slot = %.0f cycles per SIMD and wave-chunk at 2.4 GHz  (%.2fx)   "
+    const double chunks_per_simd = (double)nwg / 256 * 128;   // a workgroup's 4 waves sit on the CU's 4 SIMDs: one wave-chunk per SIMD, workgroup and chunk
+    printf("%-30s %.3f ms  %.0f ns = %.0f cycles at 2.4 GHz per wave-chunk and SIMD  (%.2fx)   "
            "D error vs float64: max %.3e  mean %.3e (mean |D| %.3e)\n",
-           names[mode], best, best * 1e6 / chunks_per_simd, best * 1e6 / chunks_per_simd * 2.4 / 4, base_ms / best, emax, esum / 4096,
+           names[mode], best, best * 1e6 / chunks_per_simd, best * 1e6 / chunks_per_simd * 2.4, base_ms / best, emax, esum / 4096,
            rsum / 4096);
   }
   return 0;
