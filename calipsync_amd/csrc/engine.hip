@@ -305,6 +305,7 @@ struct casync_engine {
   hipStream_t aux[kMaxLanes] = {};
   hipEvent_t ev_fork[kMaxLanes] = {}, ev_join[kMaxLanes] = {}, ev_done[kMaxLanes] = {}, ev_mid[kMaxLanes] = {};
   hipEvent_t ev_start = nullptr, ev_start2 = nullptr;
+  hipEvent_t ev_fwd = nullptr;   // recorded behind this handle's last forward when another handle's forward follows it (FwdGate)
   bool streams_ready = false;
   CasyncOptions opt;         // this handle's switches: process defaults at create, casync_set_option afterwards
   CasyncOptions eff;         // what the forward in progress runs under (run_forward: `opt` + the bf16 large-batch plan)
@@ -818,6 +819,36 @@ int check_forward_args(casync_handle h, const float* x, const float* a, float* o
 }  // namespace
 
 // ====================================================================== C ABI
+namespace {
+// Forwards of DIFFERENT handles on one device do not overlap on the GPU (round 6).  Two models forwarding at the same time
+// from two host threads -- an fp32 and a bf16 one -- produced sporadic wrong 2 x 16-pixel patches in the fp32 model's up3 / up4
+// outputs (tools/experiments/two_models.py: up to 30 of 30 forwards; never with two models of one precision, never beside an
+// unrelated torch load, with per-handle streams as with the shared pool; profiles/r6_two_models.txt).  Not root-caused:
+// the symptom is one wave of a fused Up block writing wrong values late.  Until it is, a forward starts behind the previous
+// forward of any OTHER handle on the device: the gate is held while a forward is enqueued; a forward that finds another
+// handle's forward in front of it records an event at the end of THAT forward's stream (everything of it is enqueued by then)
+// and waits for it.  A process with one model never records or waits: one uncontended lock per forward (an event behind every
+// forward cost 4 us per forward at B = 8: profiles/r6_two_models.txt).
+struct FwdGate {
+  std::mutex m;
+  casync_handle last = nullptr;     // the handle whose forward was enqueued last on this device ...
+  hipStream_t last_stream = nullptr;   // ... and the caller's stream it ended on (its lanes join there before it returns)
+};
+FwdGate& fwd_gate(int device) {
+  static FwdGate gates[64];
+  return gates[device < 0 || device >= 64 ? 0 : device];
+}
+struct StreamPool {
+  std::mutex m;
+  hipStream_t lane[casync_engine::kMaxLanes] = {};   // [0] unused (caller's stream)
+  hipStream_t aux[casync_engine::kMaxLanes] = {};
+};
+StreamPool& stream_pool(int device) {
+  static StreamPool pools[64];
+  return pools[device < 0 || device >= 64 ? 0 : device];
+}
+}  // namespace
+
 extern "C" {
 
 int casync_abi_version(void) { return CASYNC_ABI_VERSION; }
@@ -900,6 +931,12 @@ int casync_create_ex(int device_id, int dtype, casync_handle* out) {
 void casync_destroy(casync_handle h) {
   if (!h) return;
   DeviceGuard guard(h->device);
+  {
+    FwdGate& gate = fwd_gate(h->device);
+    std::lock_guard<std::mutex> lock(gate.m);
+    if (gate.last == h) gate.last = nullptr;
+    if (h->ev_fwd) { (void)hipEventSynchronize(h->ev_fwd); (void)hipEventDestroy(h->ev_fwd); h->ev_fwd = nullptr; }
+  }
   if (h->streams_ready) {
     for (int l = 0; l < casync_engine::kMaxLanes; ++l) {
       if (h->lane_s[l]) (void)hipStreamSynchronize(h->lane_s[l]);   // (the streams belong to the process-wide pool: drained, not destroyed)
@@ -967,17 +1004,6 @@ int casync_load_weights_device(casync_handle h, const float* packed_dev, int64_t
 // carried the first model's and serialised behind each other; `bench.py`'s bf16 leg inside the fp32 run read 42 k for the
 // same reason.  Streams only order work: two handles that share them stay correct (every forward orders itself with its
 // handle's own events), two forwards running at the same time share the queues -- as they did before.
-namespace {
-struct StreamPool {
-  std::mutex m;
-  hipStream_t lane[casync_engine::kMaxLanes] = {};   // [0] unused (caller's stream)
-  hipStream_t aux[casync_engine::kMaxLanes] = {};
-};
-StreamPool& stream_pool(int device) {
-  static StreamPool pools[64];
-  return pools[device < 0 || device >= 64 ? 0 : device];
-}
-}  // namespace
 
 static int ensure_streams(casync_handle h, int lanes, bool need_aux) {   // caller holds a DeviceGuard for h->device
   if (!h->streams_ready) {
@@ -1045,6 +1071,19 @@ static int run_forward(casync_handle h, const FwdArgs& A, hipStream_t caller, st
   DeviceGuard guard(h->device);
   CASYNC_CHECK_HIP(guard.err);
   const bool serial = prof != nullptr;
+  FwdGate& gate = fwd_gate(h->device);
+  std::unique_lock<std::mutex> gate_lock(gate.m);          // held until this forward is enqueued
+  if (gate.last && gate.last != h) {
+    if (!gate.last->ev_fwd) CASYNC_CHECK_HIP(hipEventCreateWithFlags(&gate.last->ev_fwd, hipEventDisableTiming));
+    if (hipEventRecord(gate.last->ev_fwd, gate.last_stream) == hipSuccess) {
+      CASYNC_CHECK_HIP(hipStreamWaitEvent(caller, gate.last->ev_fwd, 0));
+    } else {                          // (the other forward's stream is gone: its work is done or the device will tell)
+      (void)hipGetLastError();
+      CASYNC_CHECK_HIP(hipDeviceSynchronize());
+    }
+  }
+  gate.last = h;
+  gate.last_stream = caller;
   const bool overlap = o.overlap != 0 && !serial;
   int lanes = o.lanes < 1 ? 1 : (o.lanes > casync_engine::kMaxLanes ? casync_engine::kMaxLanes : o.lanes);
   if (A.batch < kMinLaneBatch * lanes) lanes = 1;  // small batches are latency-bound: cutting them only adds launches

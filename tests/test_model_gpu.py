@@ -496,3 +496,39 @@ def test_workspace_is_reused_across_batch_sizes(net):
     assert net._workspace is ws
     assert (small - big[:4]).abs().max() < 1e-5
     assert torch.equal(net(xt, at), big)
+
+
+def test_two_models_on_two_threads_share_the_stream_pool(net, net_bf16):
+    """Round 6: the engine's lane / audio streams are ONE process-wide set per device that every handle borrows.  Two models
+    (fp32: two lanes + audio streams; bf16: its three-lane plan) forwarding at the same time from two host threads, each on a
+    torch stream of its own, interleave their launches on those shared streams; every result must still equal the model's
+    own single-threaded result bit for bit (a forward orders itself with its handle's events, the streams only queue)."""
+    import threading
+    x, a = recipe.make_inputs_range(0, 96)
+    xt, at = torch.from_numpy(x).cuda(), torch.from_numpy(a).cuda()
+    x512, a512 = xt.repeat(3, 1, 1, 1)[:264].contiguous(), at.repeat(3, 1, 1, 1)[:264].contiguous()   # >= bf16_plan frames: three lanes
+    ref32, ref16 = net(xt, at).clone(), net_bf16(x512, a512).clone()
+    torch.cuda.synchronize()
+    bad, err = [], []
+
+    def work(model, xin, ain, ref, name):
+        try:
+            torch.cuda.set_device(0)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for i in range(6):
+                    out = model(xin, ain)
+                    s.synchronize()
+                    if not torch.equal(out, ref):
+                        bad.append((name, i))
+        except Exception as exc:
+            err.append(exc)
+
+    ts = [threading.Thread(target=work, args=(net, xt, at, ref32, "fp32")),
+          threading.Thread(target=work, args=(net_bf16, x512, a512, ref16, "bf16"))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not err, err
+    assert not bad, bad

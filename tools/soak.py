@@ -22,13 +22,14 @@ for prec in ("fp32", "bf16"):
     nets[prec].load_state_dict(sd)
 xs, aud = recipe.make_inputs(96)
 xs, aud = torch.from_numpy(xs).to(dev), torch.from_numpy(aud).to(dev)
-feats = torch.randn(400, 2, 1024, device=dev)
+xs, aud = xs.repeat(3, 1, 1, 1)[:264].contiguous(), aud.repeat(3, 1, 1, 1)[:264].contiguous()   # 264 frames: the bf16 engine's three-lane plan (round 6)
+feats = torch.randn(600, 2, 1024, device=dev)
 first, n, flips = {}, 0, 0
 rng = np.random.default_rng(0)
 t_end = time.time() + budget
 while time.time() < t_end:
     prec = "fp32" if rng.random() < 0.7 else "bf16"
-    b = int(rng.choice([1, 2, 5, 8, 11, 12, 31, 32, 33, 63, 64, 65, 96]))
+    b = int(rng.choice([1, 2, 5, 8, 11, 12, 31, 32, 33, 63, 64, 65, 96] + ([264] if rng.random() < 0.15 else [])))
     form = int(rng.integers(0, 2))
     net = nets[prec]
     if form == 0:
