@@ -53,6 +53,17 @@ __device__ __forceinline__ UpsTap ups_tap(float scale, int dst, int n_in) {
   t.l0 = 1.f - t.l1;
   return t;
 }
+// (n_out / 2 - 1) / (n_out - 1): the scale of the x2 align_corners=True upsample.  The model's resolutions are folded at compile
+// time (the same correctly rounded quotients the runtime division gives), other sizes divide.
+__device__ __forceinline__ float ups_scale(int n_out) {
+  switch (n_out) {
+    case 20: return 9.f / 19.f;
+    case 40: return 19.f / 39.f;
+    case 80: return 39.f / 79.f;
+    case 160: return 79.f / 159.f;
+  }
+  return (float)((n_out >> 1) - 1) / (float)(n_out - 1);
+}
 __device__ __forceinline__ f32x4 ups_lerp(const UpsTap& ty, const UpsTap& tx, f32x4 v00, f32x4 v01, f32x4 v10, f32x4 v11) {
 #pragma clang fp contract(off)
   const f32x4 top = tx.l0 * v00 + tx.l1 * v01;

@@ -1073,7 +1073,8 @@ static int run_forward(casync_handle h, const FwdArgs& A, hipStream_t caller, st
   const bool serial = prof != nullptr;
   FwdGate& gate = fwd_gate(h->device);
   std::unique_lock<std::mutex> gate_lock(gate.m);          // held until this forward is enqueued
-  if (gate.last && gate.last != h) {
+  static const bool gate_off = getenv("CASYNC_NO_FWD_GATE") != nullptr;   // diagnosis only (tools/experiments/two_models.py)
+  if (!gate_off && gate.last && gate.last != h) {
     if (!gate.last->ev_fwd) CASYNC_CHECK_HIP(hipEventCreateWithFlags(&gate.last->ev_fwd, hipEventDisableTiming));
     if (hipEventRecord(gate.last->ev_fwd, gate.last_stream) == hipSuccess) {
       CASYNC_CHECK_HIP(hipStreamWaitEvent(caller, gate.last->ev_fwd, 0));

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
   [[maybe_unused]] unsigned gsrc[G::NWG];   // byte offsets from `lo`
   if constexpr (UPG) {
     const int Hl = H >> 1, Wl = W >> 1;
-    const float sy = (float)(Hl - 1) / (float)(H - 1), sx = (float)(Wl - 1) / (float)(W - 1);
+    const float sy = ups_scale(H), sx = ups_scale(W);
     gy0 = ups_tap(sy, iy0 < 0 ? 0 : iy0, Hl).i0;
     gx0 = ups_tap(sx, ix0 < 0 ? 0 : ix0, Wl).i0;
 #pragma unroll
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
       const T* src = inb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * ld_in + 4 * q;
       // same arithmetic as upsample2x_kernel / ATen: src = dst*(in-1)/(out-1), l1 = frac, l0 = 1-l1
       const int Hl = H >> 1, Wl = W >> 1;
-      const float sy = (float)(Hl - 1) / (float)(H - 1), sx = (float)(Wl - 1) / (float)(W - 1);
+      const float sy = ups_scale(H), sx = ups_scale(W);
       const UpsTap ty = ups_tap(sy, ok ? iy : 0, Hl), tx = ups_tap(sx, ok ? ix : 0, Wl);
       const T* lb = lo + (size_t)b * Hl * Wl * ld_lo + 4 * q;
       const T* p00 = lb + ((size_t)ty.i0 * Wl + tx.i0) * ld_lo;
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
   [[maybe_unused]] f32x4 gw[G::MT1];
   if constexpr (UPG) {
     const int Hl = H >> 1, Wl = W >> 1;
-    const float sy = (float)(Hl - 1) / (float)(H - 1), sx = (float)(Wl - 1) / (float)(W - 1);
+    const float sy = ups_scale(H), sx = ups_scale(W);
 #pragma unroll
     for (int i = 0; i < G::MT1; ++i) {
       const int iy = iy0 + hyv[i], ix = ix0 + hxv[i];
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(256, (IRGeomB<CIN, COUT, STRIDE>::min_waves)) void 
       const int Hl = H >> 1, Wl = W >> 1;
       const __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(lo + (size_t)b * Hl * Wl * ld_lo), 0,
                                                                                (unsigned)Hl * Wl * ld_lo * 2u, 0x00020000);
-      const float sy = (float)(Hl - 1) / (float)(H - 1), sx = (float)(Wl - 1) / (float)(W - 1);
+      const float sy = ups_scale(H), sx = ups_scale(W);
       const float fy = sy * (ok ? iy : 0), fx = sx * (ok ? ix : 0);
       const int y0 = (int)fy, x0 = (int)fx;
       const int y1 = y0 + (y0 < Hl - 1), x1 = x0 + (x0 < Wl - 1);

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void dw3x3_ups_lds_kernel(const float* __restr
   const int WP = W + 2, Hl = H >> 1, Wl = W >> 1;
   const float* preb = pre + (size_t)b * H * W * C + c0;
   const float* gb = g + (size_t)b * Hl * Wl * ldg + c0;
-  const float sy = (float)(Hl - 1) / (float)(H - 1), sx = (float)(Wl - 1) / (float)(W - 1);
+  const float sy = ups_scale(H), sx = ups_scale(W);
   const int n_in = (th + 2) * WP * CSV;
   const int cv = tid % CSV, c = c0 + cv * 4;
   f32x4 wt[9];
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ i
   t /= Wo;
   const int oy = (int)(t % Ho);
   const int b = (int)(t / Ho);
-  const float sy = (float)(H - 1) / (float)(Ho - 1), sx = (float)(W - 1) / (float)(Wo - 1);
+  const float sy = ups_scale(Ho), sx = ups_scale(Wo);
   const UpsTap ty = ups_tap(sy, oy, H), tx = ups_tap(sx, ox, W);
   const T* base = in + (size_t)b * H * W * C + c;
   const f32x4 v00 = ld4(base + ((size_t)ty.i0 * W + tx.i0) * C);
