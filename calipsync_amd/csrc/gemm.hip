@@ -114,8 +114,9 @@ __device__ __forceinline__ void epilogue_rows_cols(const float* Cs, int m0, int 
     if constexpr (EUPS) {
       const int hw = epi.ups_h * epi.ups_w, Hl = epi.ups_h >> 1, Wl = epi.ups_w >> 1;
       const int b = m / hw, rem = m - b * hw, y = rem / epi.ups_w, x = rem - y * epi.ups_w;
-      const UpsTap ty = ups_tap(ups_scale(epi.ups_h), y, Hl);
-      const UpsTap tx = ups_tap(ups_scale(epi.ups_w), x, Wl);
+      // (the runtime division stays here: ups_scale()'s switch costs this epilogue 8 registers = its fourth wave per SIMD)
+      const UpsTap ty = ups_tap((float)(Hl - 1) / (float)(epi.ups_h - 1), y, Hl);
+      const UpsTap tx = ups_tap((float)(Wl - 1) / (float)(epi.ups_w - 1), x, Wl);
       const T* g = static_cast<const T*>(epi.ups_src) + (size_t)b * Hl * Wl * epi.ups_ld + n;
 #pragma unroll
       for (int e = 0; e < CPT; e += 4) {
