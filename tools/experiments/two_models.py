@@ -94,6 +94,10 @@ class Copy:
 only = os.environ.get("ONLY")
 if only:
     cases.clear()
+cases["fp32 + fp32 (264 frames, default options)"] = lambda: [(make("fp32"), xt, at), (make("fp32"), xb, ab)]
+cases["fp32 + fp32 (264 frames, lanes=1 overlap=0)"] = lambda: [(make("fp32"), xt, at), (make("fp32", lanes=1, overlap=0), xb, ab)]
+cases["fp32 + fp32 (264 frames, lanes=3 overlap=0)"] = lambda: [(make("fp32"), xt, at), (make("fp32", lanes=3, overlap=0), xb, ab)]
+cases["fp32 + bf16 (96 frames, round-5 kernels)"] = lambda: [(make("fp32"), xt, at), (make("bf16", bf16_plan=0, ir_dw_mfma=0), xt, at)]
 cases["fp32 + a bf16 matmul load"] = lambda: [(make("fp32"), xt, at), (Load16(), xt, at)]
 cases["fp32 + 1 GiB fp32 copies"] = lambda: [(make("fp32"), xt, at), (Copy(), xt, at)]
 cases["fp32 + 0.5 GiB bf16 copies"] = lambda: [(make("fp32"), xt, at), (Copy(torch.bfloat16), xt, at)]
