@@ -64,11 +64,23 @@ __device__ __forceinline__ float ups_scale(int n_out) {
   }
   return (float)((n_out >> 1) - 1) / (float)(n_out - 1);
 }
+// (element by element, each value pinned in a register: the compiler would otherwise pack the arithmetic into v_pk_mul_f32 /
+//  v_pk_add_f32 with a broadcast weight -- the packed forms that round 6 found computing wrong values beside another wave's bf16
+//  matrix instructions, profiles/r6_two_models.txt.  Same operations in the same order: the same bits as before.)
 __device__ __forceinline__ f32x4 ups_lerp(const UpsTap& ty, const UpsTap& tx, f32x4 v00, f32x4 v01, f32x4 v10, f32x4 v11) {
 #pragma clang fp contract(off)
-  const f32x4 top = tx.l0 * v00 + tx.l1 * v01;
-  const f32x4 bot = tx.l0 * v10 + tx.l1 * v11;
-  return ty.l0 * top + ty.l1 * bot;
+  f32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float a = tx.l0 * v00[e], b = tx.l1 * v01[e], c = tx.l0 * v10[e], d = tx.l1 * v11[e];
+    asm("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    float top = a + b, bot = c + d;
+    asm("" : "+v"(top), "+v"(bot));
+    float t2 = ty.l0 * top, b2 = ty.l1 * bot;
+    asm("" : "+v"(t2), "+v"(b2));
+    r[e] = t2 + b2;
+  }
+  return r;
 }
 
 // thread-local error text behind casync_last_error()

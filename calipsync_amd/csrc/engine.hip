@@ -822,13 +822,14 @@ int check_forward_args(casync_handle h, const float* x, const float* a, float* o
 namespace {
 // Forwards of DIFFERENT handles on one device do not overlap on the GPU (round 6).  Two models forwarding at the same time
 // from two host threads -- an fp32 and a bf16 one -- produced sporadic wrong 2 x 16-pixel patches in the fp32 model's up3 / up4
-// outputs (tools/experiments/two_models.py: up to 30 of 30 forwards; never with two models of one precision, never beside an
-// unrelated torch load, with per-handle streams as with the shared pool; profiles/r6_two_models.txt).  Not root-caused:
-// the symptom is one wave of a fused Up block writing wrong values late.  Until it is, a forward starts behind the previous
-// forward of any OTHER handle on the device: the gate is held while a forward is enqueued; a forward that finds another
+// outputs (tools/experiments/two_models.py: up to 30 of 30 forwards; profiles/r6_two_models.txt).  Traced to packed fp32
+// instructions at two sites (the fused Up block's G accumulation, ups_lerp()) returning wrong values while another wave of the
+// SIMD executes bf16 matrix instructions; both sites are scalar now and the pair is clean with this gate switched off.  The
+// gate stays as a second line -- the operand pattern the hardware trips on was not characterised: a forward starts behind
+// the previous forward of any OTHER handle on the device: the gate is held while a forward is enqueued; a forward that finds another
 // handle's forward in front of it records an event at the end of THAT forward's stream (everything of it is enqueued by then)
 // and waits for it.  A process with one model never records or waits: one uncontended lock per forward (an event behind every
-// forward cost 4 us per forward at B = 8: profiles/r6_two_models.txt).
+// forward cost 4 us per forward at B = 8).
 struct FwdGate {
   std::mutex m;
   casync_handle last = nullptr;     // the handle whose forward was enqueued last on this device ...

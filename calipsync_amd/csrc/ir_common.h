@@ -62,6 +62,15 @@ __device__ __forceinline__ float vmax_raw(float a, float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// v += w * g as four v_fma_f32 (asm: the compiler would pack them into two v_pk_fma_f32; see the fused block's UPG epilogue for why not)
+__device__ __forceinline__ void fma4_scalar(f32x4& v, float w, f32x4 g) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float x = v[e];
+    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(x) : "v"(w), "v"(g[e]));
+    v[e] = x;
+  }
+}
 __device__ __forceinline__ f32x4 lrelu4(f32x4 v) {
   const f32x4 s = v * CASYNC_LRELU_SLOPE;
   return f32x4{vmax_raw(v.x, s.x), vmax_raw(v.y, s.y), vmax_raw(v.z, s.z), vmax_raw(v.w, s.w)};

@@ -452,10 +452,16 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
           f32x4 v = acc[i][n];
           if constexpr (UPG) {   // + up(G)[pixel][these four channels]: four fused multiply-adds per channel
             const float* g0 = sG + PAR * G::GBUF + go[i] + 16 * n;
-            v += gw[i][0] * *reinterpret_cast<const f32x4*>(g0);
-            v += gw[i][1] * *reinterpret_cast<const f32x4*>(g0 + CC);
-            v += gw[i][2] * *reinterpret_cast<const f32x4*>(g0 + G::GW * CC);
-            v += gw[i][3] * *reinterpret_cast<const f32x4*>(g0 + G::GW * CC + CC);
+            // SCALAR v_fma_f32, not v_pk_fma_f32 (which the compiler makes of `v += w * g`): round 6 found this epilogue -- packed
+            // FMAs with a broadcast weight accumulating into registers an MFMA of this wave has just written, further MFMAs in
+            // flight -- computing wrong 16-pixel tiles whenever ANOTHER wave of the SIMD executes bf16 matrix instructions (a
+            // bf16 128x128 GEMM of a second model: 146-179 of 200 launches wrong; a register-only v_mfma_f32_16x16x32_bf16 loop
+            // that shares nothing with this kernel: 19 of 200; the scalar form: 0 of 200 in both.  profiles/r6_two_models.txt,
+            // tools/experiments/op_beside_model.py).  Same arithmetic, same bits, the same issue cycles (a packed fp32 FMA takes two).
+            fma4_scalar(v, gw[i][0], *reinterpret_cast<const f32x4*>(g0));
+            fma4_scalar(v, gw[i][1], *reinterpret_cast<const f32x4*>(g0 + CC));
+            fma4_scalar(v, gw[i][2], *reinterpret_cast<const f32x4*>(g0 + G::GW * CC));
+            fma4_scalar(v, gw[i][3], *reinterpret_cast<const f32x4*>(g0 + G::GW * CC + CC));
           }
           v = lrelu4(v);
           if (border) {   // workgroup-uniform and a real branch (the asm keeps it from becoming selects): interior tiles pay nothing

@@ -199,6 +199,16 @@ if os.environ.get("TWO_KERNELS"):
         torch.cuda.synchronize()
         ref_out = out.clone()
         print("victim:", which)
+    if os.environ.get("BURN"):
+        # register-only matrix-instruction loops as the co-runner (tools/experiments/ubench/mfma_burn.hip, built to $BURN)
+        import ctypes
+        burn = ctypes.CDLL(os.environ["BURN"]).burn
+        burn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        sink = torch.zeros(256, device=dev)
+        for kind, name in ((0, "v_mfma_f32_32x32x16_bf16"), (1, "v_mfma_f32_16x16x32_bf16"), (2, "v_mfma_f32_32x32x2_f32"), (3, "v_mfma_f32_16x16x4_f32"),
+                           (4, "v_pk_fma_f32 only")):
+            beside_op("a register-only loop of " + name, lambda s, k=kind: burn(k, 20000, 1024, s, sink.data_ptr()))
+        sys.exit(0)
     beside_op("nothing", lambda s: None)
     beside_op("bf16 GEMM 25600x1024x512, default tile", g16)
     beside_op("fp32 GEMM 25600x1024x512, default tile", g32)
