@@ -64,9 +64,9 @@ __device__ __forceinline__ float ups_scale(int n_out) {
   }
   return (float)((n_out >> 1) - 1) / (float)(n_out - 1);
 }
-// (element by element, each value pinned in a register: the compiler would otherwise pack the arithmetic into v_pk_mul_f32 /
-//  v_pk_add_f32 with a broadcast weight -- the packed forms that round 6 found computing wrong values beside another wave's bf16
-//  matrix instructions, profiles/r6_two_models.txt.  Same operations in the same order: the same bits as before.)
+// (element by element, each value pinned in a register.  With the vector form the un-fused Up path (fuse_ir=0) returned wrong
+//  patches in 40 of 40 forwards beside a second, bf16 model, with this form in none; as in the fused Up block it is the schedule
+//  that differs, not a forbidden instruction: profiles/r6_two_models.txt.  Same operations in the same order: the same bits.)
 __device__ __forceinline__ f32x4 ups_lerp(const UpsTap& ty, const UpsTap& tx, f32x4 v00, f32x4 v01, f32x4 v10, f32x4 v11) {
 #pragma clang fp contract(off)
   f32x4 r;

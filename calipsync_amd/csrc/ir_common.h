@@ -62,12 +62,17 @@ __device__ __forceinline__ float vmax_raw(float a, float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-// v += w * g as four v_fma_f32 (asm: the compiler would pack them into two v_pk_fma_f32; see the fused block's UPG epilogue for why not)
+// v += w * g as four scalar fused multiply-adds (the vector form compiles to two v_pk_fma_f32 and, in the fused Up block, to a
+// schedule that goes wrong beside another wave's bf16 matrix instructions: see its P1 epilogue).  The FMA itself is the
+// compiler's own instruction and only its RESULT passes through an empty asm (which keeps the four from being packed): an
+// instruction written in inline asm is invisible to the compiler's hazard recogniser, which then inserts none of the wait states
+// gfx950 needs between an MFMA's write and a vector instruction's read of that register (tried: `v_mfma ...; asm("v_fma_f32 ...")`
+// compiles back to back, the same FMA as a builtin gets its s_nop 8).
 __device__ __forceinline__ void fma4_scalar(f32x4& v, float w, f32x4 g) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    float x = v[e];
-    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(x) : "v"(w), "v"(g[e]));
+    float x = __builtin_fmaf(w, g[e], v[e]);
+    asm("" : "+v"(x));
     v[e] = x;
   }
 }

@@ -452,12 +452,15 @@ __global__ __launch_bounds__(256, (ir_min_waves<CIN, COUT, STRIDE, CC, UPS == 2>
           f32x4 v = acc[i][n];
           if constexpr (UPG) {   // + up(G)[pixel][these four channels]: four fused multiply-adds per channel
             const float* g0 = sG + PAR * G::GBUF + go[i] + 16 * n;
-            // SCALAR v_fma_f32, not v_pk_fma_f32 (which the compiler makes of `v += w * g`): round 6 found this epilogue -- packed
-            // FMAs with a broadcast weight accumulating into registers an MFMA of this wave has just written, further MFMAs in
-            // flight -- computing wrong 16-pixel tiles whenever ANOTHER wave of the SIMD executes bf16 matrix instructions (a
-            // bf16 128x128 GEMM of a second model: 146-179 of 200 launches wrong; a register-only v_mfma_f32_16x16x32_bf16 loop
-            // that shares nothing with this kernel: 19 of 200; the scalar form: 0 of 200 in both.  profiles/r6_two_models.txt,
-            // tools/experiments/op_beside_model.py).  Same arithmetic, same bits, the same issue cycles (a packed fp32 FMA takes two).
+            // Written element by element (fma4_scalar), NOT as `v += w * g`.  Round 6: the build with the vector form returned wrong
+            // 16-pixel tiles of E whenever ANOTHER wave of the SIMD ran bf16 matrix instructions (a bf16 128x128 GEMM of a second
+            // model: 146-183 of 200 launches wrong; a register-only v_mfma_f32_16x16x32_bf16 loop: 19 of 200; alone, or beside
+            // fp32 work: never), the build with this form never does.  It is NOT the packed instruction: patched IN PLACE in the
+            // failing binary, all 22 v_pk_fma_f32 -> v_fma_f32 pairs, it fails as before; what the failing binary needs is >= 64
+            // idle issue slots between a tile's E store and the next tile's G accumulation (170 -> 3-20 of 200; waits on the
+            // LDS reads, on the stores, at the barriers, or register renames: nothing).  So this form is kept for the schedule the
+            // compiler makes of it, not for a rule, and tests/test_model_gpu.py::test_fused_up_block_beside_a_looping_bf16_gemm
+            // checks every rebuild (profiles/r6_two_models.txt sections 5-8; tools/experiments/binpatch/).
             fma4_scalar(v, gw[i][0], *reinterpret_cast<const f32x4*>(g0));
             fma4_scalar(v, gw[i][1], *reinterpret_cast<const f32x4*>(g0 + CC));
             fma4_scalar(v, gw[i][2], *reinterpret_cast<const f32x4*>(g0 + G::GW * CC));

@@ -72,3 +72,4 @@ def test_no_kernel_spills(table):
 def test_tuned_kernels_keep_their_occupancy(table):
     low = {k: (table[k]["vgprs"], table[k]["waves"], want) for k, want in MIN_WAVES.items() if table[k]["waves"] < want}
     assert not low, f"(registers, waves/SIMD now, waves/SIMD pinned): {low}"
+

@@ -17,7 +17,7 @@ lib = _lib.load()
 sd_np = recipe.make_state_dict()
 sd = {k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}
 folded = pack.fold(sd_np)
-x, a = recipe.make_inputs_range(0, 96)
+x, a = recipe.make_inputs_range(0, int(os.environ.get("FRAMES", "96")))   # FRAMES=8: the small-batch plan (pw_dw deep ring, single lane)
 xt, at = torch.from_numpy(x).to(dev), torch.from_numpy(a).to(dev)
 net = Model(6, "hubert").to(dev)
 net.load_state_dict(sd)
