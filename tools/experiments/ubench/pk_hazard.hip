@@ -129,6 +129,8 @@ __global__ __launch_bounds__(256, 4) void victim(unsigned* counts, Sample* first
 //   14  as 9 behind another fp32 MFMA of this wave (the pipe busy with the wave's own work)
 //   15  as 9 with v_mfma_f32_16x16x32_bf16 (an XDL instruction WITHOUT the wait states the compiler would insert: what a violated
 //       hazard looks like in this harness)
+//   16  behind a run of eight independent fp32 MFMAs of this wave (as the kernel issues them): the A operand register of the LAST one
+//       written at +1                      17  its B operand                      18  its SrcC[2] (vDst != SrcC)
 #define WAR_HEAD "v_mov_b32 v40, %[c0]\n\tv_mov_b32 v41, %[c0]\n\tv_mov_b32 v42, %[c0]\n\tv_mov_b32 v43, %[c0]\n\tv_mov_b32 v48, 0\n\ts_nop 7\n\t"
 #define WAR_TAIL(D0, D1, D2, D3) "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\tv_mov_b32 %[r0], " D0 "\n\tv_mov_b32 %[r1], " D1 "\n\tv_mov_b32 %[r2], " D2 "\n\tv_mov_b32 %[r3], " D3 "\n\t"
 #define WAR_OPS : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3) : [a] "v"(al), [b] "v"(two), [c0] "v"(c0), [junk] "v"(junk)
@@ -158,7 +160,21 @@ __global__ __launch_bounds__(256, 4) void victim_war(unsigned* counts, Sample* f
     else if constexpr (FORM == 14)
       asm volatile(WAR_HEAD "v_mfma_f32_16x16x4_f32 v[50:53], %[b], %[a], 0\n\tv_mfma_f32_16x16x4_f32 v[44:47], %[a], %[b], v[40:43]\n\tv_mov_b32 v42, %[junk]\n\t"
                    WAR_TAIL("v44", "v45", "v46", "v47") WAR_OPS WAR_CLOB);
-    else {
+    else if constexpr (FORM >= 16) {
+#define RUN8 "v_mfma_f32_16x16x4_f32 v[60:63], %[b], %[a], 0\n\tv_mfma_f32_16x16x4_f32 v[64:67], %[b], %[a], 0\n\tv_mfma_f32_16x16x4_f32 v[68:71], %[b], %[a], 0\n\t" \
+             "v_mfma_f32_16x16x4_f32 v[72:75], %[b], %[a], 0\n\tv_mfma_f32_16x16x4_f32 v[60:63], %[a], %[b], v[60:63]\n\tv_mfma_f32_16x16x4_f32 v[64:67], %[a], %[b], v[64:67]\n\t" \
+             "v_mfma_f32_16x16x4_f32 v[68:71], %[a], %[b], v[68:71]\n\tv_mfma_f32_16x16x4_f32 v[72:75], %[a], %[b], v[72:75]\n\t"
+#define WAR_CLOB2 WAR_CLOB, "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75"
+      if constexpr (FORM == 16)
+        asm volatile(WAR_HEAD "v_mov_b32 v58, %[a]\n\tv_mov_b32 v59, %[b]\n\ts_nop 7\n\t" RUN8 "v_mfma_f32_16x16x4_f32 v[44:47], v58, v59, v[40:43]\n\tv_mov_b32 v58, %[junk]\n\t"
+                     WAR_TAIL("v44", "v45", "v46", "v47") WAR_OPS WAR_CLOB2);
+      else if constexpr (FORM == 17)
+        asm volatile(WAR_HEAD "v_mov_b32 v58, %[a]\n\tv_mov_b32 v59, %[b]\n\ts_nop 7\n\t" RUN8 "v_mfma_f32_16x16x4_f32 v[44:47], v58, v59, v[40:43]\n\tv_mov_b32 v59, %[junk]\n\t"
+                     WAR_TAIL("v44", "v45", "v46", "v47") WAR_OPS WAR_CLOB2);
+      else
+        asm volatile(WAR_HEAD "v_mov_b32 v58, %[a]\n\tv_mov_b32 v59, %[b]\n\ts_nop 7\n\t" RUN8 "v_mfma_f32_16x16x4_f32 v[44:47], v58, v59, v[40:43]\n\tv_mov_b32 v42, %[junk]\n\t"
+                     WAR_TAIL("v44", "v45", "v46", "v47") WAR_OPS WAR_CLOB2);
+    } else {
       // bf16: A = al in every element (al <= 8 is exact), B = 2 in the first four k of every lane: 4 k x 4 lane groups x al x 2 = 32 al ... kept
       // simple: all 8 elements al and 0.25 -> 32 x al x 0.25 = 8 al, the same expectation as the fp32 forms
       asm volatile(WAR_HEAD
@@ -218,7 +234,7 @@ static void launch_victim(int form, hipStream_t s, unsigned* counts, Sample* fir
     V(0) V(1) V(2) V(3) V(4) V(5) V(6) V(7)
 #undef V
 #define W(F) case F: hipLaunchKernelGGL(victim_war<F>, dim3(blocks), dim3(256), 0, s, counts, first, iters, seed); break;
-    W(8) W(9) W(10) W(11) W(12) W(13) W(14) W(15)
+    W(8) W(9) W(10) W(11) W(12) W(13) W(14) W(15) W(16) W(17) W(18)
 #undef W
   }
 }
@@ -232,12 +248,13 @@ static void launch_burn(int kind, hipStream_t s, float* sink, int iters, int blo
 
 int main(int argc, char** argv) {
   const int launches = argc > 1 ? atoi(argv[1]) : 100, iters = argc > 2 ? atoi(argv[2]) : 4000, blocks = 1024;
-  static const char* form_name[16] = {"pk_fma bcast, plain regs", "pk_fma pair, plain regs", "pk_fma bcast <- fresh f32 MFMA", "pk_fma pair  <- fresh f32 MFMA",
+  static const char* form_name[19] = {"pk_fma bcast, plain regs", "pk_fma pair, plain regs", "pk_fma bcast <- fresh f32 MFMA", "pk_fma pair  <- fresh f32 MFMA",
                                      "scalar fma   <- fresh f32 MFMA", "pk_fma bcast <- f32 MFMA + s_sleep 2", "pk_add       <- fresh f32 MFMA",
                                      "pk_fma bcast <- fresh bf16 MFMA",
                                       "f32 MFMA in place (control)", "f32 MFMA, SrcC[2] written at +1", "f32 MFMA, SrcC[2] written at +2", "f32 MFMA, SrcC[2] written at +4",
                                       "f32 MFMA vDst overlaps SrcC, write +1", "f32 MFMA vDst overlaps SrcC, no write", "f32 MFMA behind own MFMA, write +1",
-                                      "bf16 MFMA (XDL), SrcC[2] written at +1"};
+                                      "bf16 MFMA (XDL), SrcC[2] written at +1",
+                                      "f32 MFMA behind 8 MFMAs, A written +1", "f32 MFMA behind 8 MFMAs, B written +1", "f32 MFMA behind 8 MFMAs, SrcC[2] written +1"};
   static const char* burn_name[6] = {"32x32x16_bf16", "16x16x32_bf16", "32x32x2_f32", "16x16x4_f32", "pk_fma only", "nothing"};
   float hseed[1280];
   for (int i = 0; i < 1280; ++i) hseed[i] = 0.37f + 0.0131f * (float)((i * 2654435761u) % 97);
@@ -260,7 +277,7 @@ int main(int argc, char** argv) {
   printf("%-40s", "victim form \\ co-runner");
   for (int k = 0; k < 6; ++k) printf(" %16s", burn_name[k]);
   printf("\n");
-  const int form_lo = argc > 3 ? atoi(argv[3]) : 0, form_hi = argc > 4 ? atoi(argv[4]) : 15;
+  const int form_lo = argc > 3 ? atoi(argv[3]) : 0, form_hi = argc > 4 ? atoi(argv[4]) : 18;
   for (int form = form_lo; form <= form_hi; ++form) {
     printf("%-40s", form_name[form]);
     Sample keep{};
