@@ -1,3 +1,7 @@
+// RESULT (forms 19-24, profiles/r6_two_models.txt section 9): on gfx950 a packed fp32 instruction whose LOW result takes the HIGH half of its
+// second source (op_sel:[x,1,..]) reads that half as zero on lanes 48..63 beside another wave's v_mfma_f32_16x16x32_bf16 -- 200 of 200 launches;
+// every other form below: never.
+//
 // Round 6: which instruction pattern returns wrong values beside ANOTHER wave's matrix instructions?  (profiles/r6_two_models.txt:
 // the fp32 fused Up block computed wrong 16-pixel tiles whenever a bf16 GEMM of a second model shared the chip; its P1 epilogue
 // `v += w * g` as scalar FMAs instead of v_pk_fma_f32 made that go away.)  This is the pattern without the kernel around it.
@@ -196,6 +200,59 @@ __global__ __launch_bounds__(256, 4) void victim_war(unsigned* counts, Sample* f
   if (bad) atomicAdd(&counts[0], bad);
 }
 
+// ---- forms 19..22: packed fp32 instructions whose LOW result takes the HIGH half of an operand (op_sel) -------------------------
+// The debug build of the failing kernel (tools/experiments/upg_dump.py) showed which instruction goes wrong there: the one FMA of the
+// four whose weight sits in the high half of its register pair, `v_pk_fma_f32 v[54:55], v[54:55], v[96:97], v[58:59] op_sel:[0,1,0]`,
+// returns its ADDEND in the low half of the result on lanes 48..63 (the product is missing), nothing else.
+//   19  v_pk_fma_f32 d, t, w, c op_sel:[0,1,0], d = t in place (that instruction)     20  the same, d a fresh pair
+//   21  v_pk_fma_f32 op_sel:[1,0,0] (low result from the high half of src0)             22  v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[0,1] (src0 again)
+//   23  v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0] (low result from the high half of src1: the ORIGINAL failing build's bilinear weights)
+//   24  v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]
+template <int FORM>
+__global__ __launch_bounds__(256, 4) void victim_opsel(unsigned* counts, Sample* first, int iters, const float* seed) {
+  const float s0 = seed[threadIdx.x], s1 = seed[256 + threadIdx.x], s2 = seed[512 + threadIdx.x], s3 = seed[768 + threadIdx.x];
+  unsigned bad = 0;
+  f32x2 c = {s2, s3};
+  for (int it = 0; it < iters; ++it) {
+    const float k = (float)(it & 7);
+    f32x2 t = {s0 + k, s1 - k}, w = {s3 * 0.5f + k, s2 + 0.25f * k}, d;
+    asm volatile("" : "+v"(t), "+v"(w), "+v"(c));
+    float e_lo, e_hi;
+    if constexpr (FORM == 19) {
+      d = t;
+      asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,1,0]" : "+v"(d) : "v"(w), "v"(c));
+      e_lo = sfma(t.x, w.y, c.x), e_hi = sfma(t.y, w.y, c.y);
+    } else if constexpr (FORM == 20) {
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=&v"(d) : "v"(t), "v"(w), "v"(c));
+      e_lo = sfma(t.x, w.y, c.x), e_hi = sfma(t.y, w.y, c.y);
+    } else if constexpr (FORM == 21) {
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0]" : "=&v"(d) : "v"(w), "v"(t), "v"(c));
+      e_lo = sfma(w.y, t.x, c.x), e_hi = sfma(w.y, t.y, c.y);
+    } else if constexpr (FORM == 22) {
+      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=&v"(d) : "v"(t), "v"(w));
+      e_lo = t.y * w.x, e_hi = t.x * w.y;
+      asm volatile("" : "+v"(e_lo), "+v"(e_hi));
+    } else if constexpr (FORM == 23) {
+      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(d) : "v"(t), "v"(w));
+      e_lo = t.x * w.y, e_hi = t.y * w.x;
+      asm volatile("" : "+v"(e_lo), "+v"(e_hi));
+    } else {
+      asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(d) : "v"(t), "v"(w));
+      e_lo = t.x + w.y, e_hi = t.y + w.x;
+      asm volatile("" : "+v"(e_lo), "+v"(e_hi));
+    }
+    const bool m0 = __float_as_uint(d.x) != __float_as_uint(e_lo), m1 = __float_as_uint(d.y) != __float_as_uint(e_hi);
+    if (m0 | m1) {
+      ++bad;
+      if (atomicAdd(&counts[1], 1u) == 0)
+        *first = Sample{(unsigned)it, (unsigned)(blockIdx.x * 256 + threadIdx.x), (unsigned)FORM, m0 ? 0u : 1u, m0 ? d.x : d.y, m0 ? e_lo : e_hi, w.y, m0 ? t.x : t.y,
+                        m0 ? c.x : c.y, 0.f};
+    }
+    c = f32x2{e_lo * 0.001f + s2, e_hi * 0.001f + s3};       // the addend changes every iteration
+  }
+  if (bad) atomicAdd(&counts[0], bad);
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void burn_kernel(float* sink, int iters) {
   const unsigned t = threadIdx.x + 1;
@@ -236,6 +293,9 @@ static void launch_victim(int form, hipStream_t s, unsigned* counts, Sample* fir
 #define W(F) case F: hipLaunchKernelGGL(victim_war<F>, dim3(blocks), dim3(256), 0, s, counts, first, iters, seed); break;
     W(8) W(9) W(10) W(11) W(12) W(13) W(14) W(15) W(16) W(17) W(18)
 #undef W
+#define O(F) case F: hipLaunchKernelGGL(victim_opsel<F>, dim3(blocks), dim3(256), 0, s, counts, first, iters, seed); break;
+    O(19) O(20) O(21) O(22) O(23) O(24)
+#undef O
   }
 }
 static void launch_burn(int kind, hipStream_t s, float* sink, int iters, int blocks) {
@@ -248,13 +308,15 @@ static void launch_burn(int kind, hipStream_t s, float* sink, int iters, int blo
 
 int main(int argc, char** argv) {
   const int launches = argc > 1 ? atoi(argv[1]) : 100, iters = argc > 2 ? atoi(argv[2]) : 4000, blocks = 1024;
-  static const char* form_name[19] = {"pk_fma bcast, plain regs", "pk_fma pair, plain regs", "pk_fma bcast <- fresh f32 MFMA", "pk_fma pair  <- fresh f32 MFMA",
+  static const char* form_name[25] = {"pk_fma bcast, plain regs", "pk_fma pair, plain regs", "pk_fma bcast <- fresh f32 MFMA", "pk_fma pair  <- fresh f32 MFMA",
                                      "scalar fma   <- fresh f32 MFMA", "pk_fma bcast <- f32 MFMA + s_sleep 2", "pk_add       <- fresh f32 MFMA",
                                      "pk_fma bcast <- fresh bf16 MFMA",
                                       "f32 MFMA in place (control)", "f32 MFMA, SrcC[2] written at +1", "f32 MFMA, SrcC[2] written at +2", "f32 MFMA, SrcC[2] written at +4",
                                       "f32 MFMA vDst overlaps SrcC, write +1", "f32 MFMA vDst overlaps SrcC, no write", "f32 MFMA behind own MFMA, write +1",
                                       "bf16 MFMA (XDL), SrcC[2] written at +1",
-                                      "f32 MFMA behind 8 MFMAs, A written +1", "f32 MFMA behind 8 MFMAs, B written +1", "f32 MFMA behind 8 MFMAs, SrcC[2] written +1"};
+                                      "f32 MFMA behind 8 MFMAs, A written +1", "f32 MFMA behind 8 MFMAs, B written +1", "f32 MFMA behind 8 MFMAs, SrcC[2] written +1",
+                                      "pk_fma op_sel:[0,1,0] in place", "pk_fma op_sel:[0,1,0]", "pk_fma op_sel:[1,0,0]", "pk_mul op_sel:[1,0] op_sel_hi:[0,1]",
+                                      "pk_mul op_sel:[0,1] op_sel_hi:[1,0]", "pk_add op_sel:[0,1] op_sel_hi:[1,0]"};
   static const char* burn_name[6] = {"32x32x16_bf16", "16x16x32_bf16", "32x32x2_f32", "16x16x4_f32", "pk_fma only", "nothing"};
   float hseed[1280];
   for (int i = 0; i < 1280; ++i) hseed[i] = 0.37f + 0.0131f * (float)((i * 2654435761u) % 97);
@@ -277,7 +339,7 @@ int main(int argc, char** argv) {
   printf("%-40s", "victim form \\ co-runner");
   for (int k = 0; k < 6; ++k) printf(" %16s", burn_name[k]);
   printf("\n");
-  const int form_lo = argc > 3 ? atoi(argv[3]) : 0, form_hi = argc > 4 ? atoi(argv[4]) : 18;
+  const int form_lo = argc > 3 ? atoi(argv[3]) : 0, form_hi = argc > 4 ? atoi(argv[4]) : 24;
   for (int form = form_lo; form <= form_hi; ++form) {
     printf("%-40s", form_name[form]);
     Sample keep{};
@@ -332,7 +394,10 @@ int main(int argc, char** argv) {
     printf("\n");
     if (have) {
       const float stale = fmaf(keep.w, keep.g, keep.c_prev), zero = fmaf(keep.w, keep.g, 0.f);
-      if (form >= 8)
+      if (form >= 19)
+        printf("    first mismatch: iteration %u, lane %u (lane %u of its wave), %s half: got %.9g, expected %.9g; weight %.9g operand %.9g addend %.9g\n", keep.it, keep.lane,
+               keep.lane & 63, keep.which ? "high" : "low", keep.p, keep.e, keep.w, keep.g, keep.c);
+      else if (form >= 8)
         printf("    first mismatch: iteration %u, lane %u, element %u: got %.9g, expected %.9g (SrcC %.9g + product %.9g; the value written over SrcC[2]: %.9g)\n", keep.it,
                keep.lane, keep.which, keep.p, keep.e, keep.w, keep.c, keep.g);
       else
