@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 4) void victim_war(unsigned* counts, Sample* f
 //   19  v_pk_fma_f32 d, t, w, c op_sel:[0,1,0], d = t in place (that instruction)     20  the same, d a fresh pair
 //   21  v_pk_fma_f32 op_sel:[1,0,0] (low result from the high half of src0)             22  v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[0,1] (src0 again)
 //   23  v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0] (low result from the high half of src1: the ORIGINAL failing build's bilinear weights)
-//   24  v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]
+//   24  v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]                 25  v_pk_fma_f32 op_sel:[0,0,1] (the ADDEND's high half into the low result)
 template <int FORM>
 __global__ __launch_bounds__(256, 4) void victim_opsel(unsigned* counts, Sample* first, int iters, const float* seed) {
   const float s0 = seed[threadIdx.x], s1 = seed[256 + threadIdx.x], s2 = seed[512 + threadIdx.x], s3 = seed[768 + threadIdx.x];
@@ -236,10 +236,13 @@ __global__ __launch_bounds__(256, 4) void victim_opsel(unsigned* counts, Sample*
       asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(d) : "v"(t), "v"(w));
       e_lo = t.x * w.y, e_hi = t.y * w.x;
       asm volatile("" : "+v"(e_lo), "+v"(e_hi));
-    } else {
+    } else if constexpr (FORM == 24) {
       asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(d) : "v"(t), "v"(w));
       e_lo = t.x + w.y, e_hi = t.y + w.x;
       asm volatile("" : "+v"(e_lo), "+v"(e_hi));
+    } else {
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1]" : "=&v"(d) : "v"(t), "v"(w), "v"(c));
+      e_lo = sfma(t.x, w.x, c.y), e_hi = sfma(t.y, w.y, c.y);
     }
     const bool m0 = __float_as_uint(d.x) != __float_as_uint(e_lo), m1 = __float_as_uint(d.y) != __float_as_uint(e_hi);
     if (m0 | m1) {
@@ -294,7 +297,7 @@ static void launch_victim(int form, hipStream_t s, unsigned* counts, Sample* fir
     W(8) W(9) W(10) W(11) W(12) W(13) W(14) W(15) W(16) W(17) W(18)
 #undef W
 #define O(F) case F: hipLaunchKernelGGL(victim_opsel<F>, dim3(blocks), dim3(256), 0, s, counts, first, iters, seed); break;
-    O(19) O(20) O(21) O(22) O(23) O(24)
+    O(19) O(20) O(21) O(22) O(23) O(24) O(25)
 #undef O
   }
 }
@@ -308,7 +311,7 @@ static void launch_burn(int kind, hipStream_t s, float* sink, int iters, int blo
 
 int main(int argc, char** argv) {
   const int launches = argc > 1 ? atoi(argv[1]) : 100, iters = argc > 2 ? atoi(argv[2]) : 4000, blocks = 1024;
-  static const char* form_name[25] = {"pk_fma bcast, plain regs", "pk_fma pair, plain regs", "pk_fma bcast <- fresh f32 MFMA", "pk_fma pair  <- fresh f32 MFMA",
+  static const char* form_name[26] = {"pk_fma bcast, plain regs", "pk_fma pair, plain regs", "pk_fma bcast <- fresh f32 MFMA", "pk_fma pair  <- fresh f32 MFMA",
                                      "scalar fma   <- fresh f32 MFMA", "pk_fma bcast <- f32 MFMA + s_sleep 2", "pk_add       <- fresh f32 MFMA",
                                      "pk_fma bcast <- fresh bf16 MFMA",
                                       "f32 MFMA in place (control)", "f32 MFMA, SrcC[2] written at +1", "f32 MFMA, SrcC[2] written at +2", "f32 MFMA, SrcC[2] written at +4",
@@ -316,7 +319,7 @@ int main(int argc, char** argv) {
                                       "bf16 MFMA (XDL), SrcC[2] written at +1",
                                       "f32 MFMA behind 8 MFMAs, A written +1", "f32 MFMA behind 8 MFMAs, B written +1", "f32 MFMA behind 8 MFMAs, SrcC[2] written +1",
                                       "pk_fma op_sel:[0,1,0] in place", "pk_fma op_sel:[0,1,0]", "pk_fma op_sel:[1,0,0]", "pk_mul op_sel:[1,0] op_sel_hi:[0,1]",
-                                      "pk_mul op_sel:[0,1] op_sel_hi:[1,0]", "pk_add op_sel:[0,1] op_sel_hi:[1,0]"};
+                                      "pk_mul op_sel:[0,1] op_sel_hi:[1,0]", "pk_add op_sel:[0,1] op_sel_hi:[1,0]", "pk_fma op_sel:[0,0,1]"};
   static const char* burn_name[6] = {"32x32x16_bf16", "16x16x32_bf16", "32x32x2_f32", "16x16x4_f32", "pk_fma only", "nothing"};
   float hseed[1280];
   for (int i = 0; i < 1280; ++i) hseed[i] = 0.37f + 0.0131f * (float)((i * 2654435761u) % 97);
@@ -339,7 +342,7 @@ int main(int argc, char** argv) {
   printf("%-40s", "victim form \\ co-runner");
   for (int k = 0; k < 6; ++k) printf(" %16s", burn_name[k]);
   printf("\n");
-  const int form_lo = argc > 3 ? atoi(argv[3]) : 0, form_hi = argc > 4 ? atoi(argv[4]) : 24;
+  const int form_lo = argc > 3 ? atoi(argv[3]) : 0, form_hi = argc > 4 ? atoi(argv[4]) : 25;
   for (int form = form_lo; form <= form_hi; ++form) {
     printf("%-40s", form_name[form]);
     Sample keep{};

@@ -10,8 +10,8 @@ launches of tools/experiments/ubench/pk_hazard.hip (forms 19, 20, 23, 24) beside
 never beside fp32 matrix instructions, vector work or nothing; `op_sel` on the FIRST source and `op_sel_hi` (the high result taking a
 low half: the usual scalar broadcast) never fail.  hipcc emits the form when a scalar factor happens to live in the high half of a
 register pair -- in round 6 the bilinear weights of the fused Up block, which made an fp32 model return wrong patches beside a bf16
-model (profiles/r6_two_models.txt section 9).  This tool lists every such instruction per kernel (the third source of an FMA is listed too:
-not tried on the hardware); tests/test_kernel_resources.py keeps the shipped library free of them.
+model (profiles/r6_two_models.txt section 9).  This tool lists every such instruction per kernel (op_sel on the THIRD source of an FMA,
+form 25 of the microbenchmark, never failed and is not listed); tests/test_kernel_resources.py keeps the shipped library free of them.
 """
 from __future__ import annotations
 
@@ -29,7 +29,7 @@ PACKED = re.compile(r"\b(v_pk_(?:fma|mul|add)_f32)\b(.*?)(?://|$)")
 
 
 def scan(asm: str):
-    """-> {kernel: [instruction text]} of packed fp32 instructions with op_sel set for the second (or third) source"""
+    """-> {kernel: [instruction text]} of packed fp32 instructions with op_sel set for the second source"""
     out, cur = {}, None
     for line in asm.splitlines():
         m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
@@ -40,7 +40,7 @@ def scan(asm: str):
         if cur is None or not mm:
             continue
         sel = re.search(r"op_sel:\[([01,]+)\]", mm.group(2))
-        if sel and "1" in sel.group(1).split(",")[1:]:
+        if sel and sel.group(1).split(",")[1:2] == ["1"]:
             out.setdefault(cur, []).append((mm.group(1) + mm.group(2)).strip())
     return out
 
@@ -64,5 +64,5 @@ if __name__ == "__main__":
         print(f"{k}: {len(v)}")
         for ins in v[:8]:
             print("     ", ins)
-    print(f"{sum(len(v) for v in hits.values())} packed fp32 instruction(s) whose low result reads the high half of src1 / src2")
+    print(f"{sum(len(v) for v in hits.values())} packed fp32 instruction(s) whose low result reads the high half of src1")
     sys.exit(1 if hits else 0)
